@@ -1,0 +1,510 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle for the spgpu-amd hot path.
+ *
+ * A plain-C restatement of what the reference (davidebarbieri/spgpu) computes
+ * on this path, each function citing the reference lines it follows (paths
+ * relative to the reference's src/core/).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this file's library; the product
+ * (spgpu_amd/lib/libspgpu.so) never links, loads or calls it.
+ *
+ * PINNING
+ *  - Format conversions (orc_cooToEll, orc_ellToHell, orc_cooToHdia, ...):
+ *    PINNED bit-exact against the reference's own converters, compiled from
+ *    /root/reference into oracle/_ref (see oracle/Makefile) and compared on
+ *    randomised inputs (tests/test_oracle_vs_reference.py), and against the
+ *    known-answer checksums of SURVEY.md section 8(a) (tests/golden/).
+ *  - SpMV / axpby / dot values: the reference has NO CPU implementation of
+ *    these kernels and NO golden output values (its tests print dot(z,z) and a
+ *    human compares formats).  Absolute values are therefore "parity
+ *    unpinned" by the reference; this oracle is pinned instead by the one
+ *    analytic identity the reference's ctest.c implies (A = 2I, alpha = 2,
+ *    beta = -3  =>  z = 4x - 3y), by the cross-format equalities its perf
+ *    tests rely on (ELL == HELL == HDIA results), and by an independent
+ *    extended-precision CSR product (tests/test_oracle_spmv.py).
+ *
+ * Every routine exists in four flavours generated from one macro body:
+ * s (float), d (double), c (float complex), z (double complex).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ======================================================================== */
+/* Type codes and sizes: core.h:51-57, core.c:82-99                          */
+/* ======================================================================== */
+size_t orc_sizeOf(int typeCode)
+{
+    static const size_t bytes[5] = {sizeof(int), sizeof(float), sizeof(double), 2 * sizeof(float), 2 * sizeof(double)};
+    return (typeCode >= 0 && typeCode < 5) ? bytes[typeCode] : 0;
+}
+
+/* FNV-1a 64-bit over raw bytes: the checksum SURVEY.md 8(a) quotes. */
+uint64_t orc_fnv1a64(const void* data, size_t bytes)
+{
+    const unsigned char* p = (const unsigned char*)data;
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (size_t i = 0; i < bytes; ++i) {
+        h ^= p[i];
+        h *= 0x100000001b3ULL;
+    }
+    return h;
+}
+
+int orc_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ======================================================================== */
+/* COO -> ELL: ell.c:5-80                                                    */
+/* ======================================================================== */
+
+/* ell.c:5-31: histogram of row indices, then the maximum. */
+void orc_computeEllRowLenghts(int* rowLen, int* maxRow, int rows, int nnz, const int* cooRows, int base)
+{
+    for (int r = 0; r < rows; ++r)
+        rowLen[r] = 0;
+    for (int e = 0; e < nnz; ++e)
+        rowLen[cooRows[e] - base]++;
+    int m = 0;
+    for (int r = 0; r < rows; ++r)
+        if (rowLen[r] > m)
+            m = rowLen[r];
+    *maxRow = m;
+}
+
+/* ell.c:33-37 */
+int orc_computeEllAllocPitch(int rows)
+{
+    return ((rows + 31) / 32) * 32;
+}
+
+/* ell.c:39-80: entry e goes to slot (row, next free k of that row); stored
+ * index = col - cooBase + ellBase; value copied verbatim. */
+void orc_cooToEll(void* ellVals, int* ellIdx, int valPitch, int idxPitch, int maxRow, int ellBase, int rows,
+                  int nnz, const int* cooRows, const int* cooCols, const void* cooVals, int cooBase, int type)
+{
+    (void)maxRow;
+    const size_t es = orc_sizeOf(type);
+    int* next = (int*)calloc(rows > 0 ? (size_t)rows : 1, sizeof(int));
+    for (int e = 0; e < nnz; ++e) {
+        const int r = cooRows[e] - cooBase;
+        const size_t k = (size_t)next[r];
+        ellIdx[(size_t)r + k * (size_t)idxPitch] = cooCols[e] - cooBase + ellBase;
+        memcpy((char*)ellVals + ((size_t)r + k * (size_t)valPitch) * es, (const char*)cooVals + (size_t)e * es, es);
+        next[r]++;
+    }
+    free(next);
+}
+
+/* ======================================================================== */
+/* ELL -> HELL: hell.c:4-104                                                 */
+/* ======================================================================== */
+
+/* hell.c:4-44: sum over hacks (last one possibly partial) of the longest row. */
+void orc_computeHellAllocSize(int* height, int hackSize, int rows, const int* rowLen)
+{
+    int total = 0;
+    const int hacks = (rows + hackSize - 1) / hackSize;
+    for (int h = 0; h < hacks; ++h) {
+        int longest = 0;
+        for (int j = 0; j < hackSize && h * hackSize + j < rows; ++j)
+            if (rowLen[h * hackSize + j] > longest)
+                longest = rowLen[h * hackSize + j];
+        total += longest;
+    }
+    *height = total;
+}
+
+/* hell.c:46-104: hackOffsets[h] = hackSize * (sum of longest rows of earlier
+ * hacks); slot of (row, k) = hackOffsets[h] + row%hackSize + k*hackSize; only
+ * k < rowLen[row] is written. */
+void orc_ellToHell(void* hellVals, int* hellIdx, int* hackOffsets, int hackSize, const void* ellVals,
+                   const int* ellIdx, int valPitch, int idxPitch, const int* rowLen, int rows, int type)
+{
+    const size_t es = orc_sizeOf(type);
+    const int hacks = (rows + hackSize - 1) / hackSize;
+    size_t offset = 0;
+    for (int h = 0; h < hacks; ++h) {
+        int longest = 0;
+        hackOffsets[h] = (int)offset;
+        for (int j = 0; j < hackSize; ++j) {
+            const int row = h * hackSize + j;
+            if (row >= rows)
+                break;
+            if (rowLen[row] > longest)
+                longest = rowLen[row];
+            for (int k = 0; k < rowLen[row]; ++k) {
+                const size_t dst = offset + (size_t)j + (size_t)k * (size_t)hackSize;
+                memcpy((char*)hellVals + dst * es,
+                       (const char*)ellVals + ((size_t)k * (size_t)valPitch + (size_t)row) * es, es);
+                hellIdx[dst] = ellIdx[(size_t)k * (size_t)idxPitch + (size_t)row];
+            }
+        }
+        offset += (size_t)hackSize * (size_t)longest;
+    }
+}
+
+/* ======================================================================== */
+/* COO -> HDIA: hdia.cpp:8-11, 161-349                                       */
+/* ======================================================================== */
+
+int orc_getHdiaHacksCount(int hackSize, int rows)
+{
+    return (rows + hackSize - 1) / hackSize;
+}
+
+/* The reference keeps, per hack, an ordered map keyed by
+ *   diagPos = hackSize - 1 + (col0 - row0 % hackSize)         (hdia.cpp:210-211)
+ * Here the ordered map is a small sorted array with insertion. */
+typedef struct { int* key; int count, cap; } orc_keyset;
+
+static int orc_keyset_find(const orc_keyset* s, int key) /* index or -1 */
+{
+    int lo = 0, hi = s->count - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) / 2;
+        if (s->key[mid] == key)
+            return mid;
+        if (s->key[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid - 1;
+    }
+    return -1;
+}
+
+static void orc_keyset_insert(orc_keyset* s, int key)
+{
+    if (orc_keyset_find(s, key) >= 0)
+        return;
+    if (s->count == s->cap) {
+        s->cap = s->cap ? 2 * s->cap : 16;
+        s->key = (int*)realloc(s->key, (size_t)s->cap * sizeof(int));
+    }
+    int i = s->count++;
+    while (i > 0 && s->key[i - 1] > key) {
+        s->key[i] = s->key[i - 1];
+        --i;
+    }
+    s->key[i] = key;
+}
+
+/* Entries grouped by hack in COO order (hdia.cpp:180-191 push_back per hack). */
+static void orc_groupByHack(int** startOut, int** listOut, int hacks, int hackSize, int nnz, const int* cooRows, int base)
+{
+    int* start = (int*)calloc((size_t)hacks + 1, sizeof(int));
+    int* list = (int*)malloc((nnz > 0 ? (size_t)nnz : 1) * sizeof(int));
+    for (int e = 0; e < nnz; ++e)
+        start[(cooRows[e] - base) / hackSize + 1]++;
+    for (int h = 0; h < hacks; ++h)
+        start[h + 1] += start[h];
+    int* fill = (int*)malloc(((size_t)hacks + 1) * sizeof(int));
+    memcpy(fill, start, ((size_t)hacks + 1) * sizeof(int));
+    for (int e = 0; e < nnz; ++e)
+        list[fill[(cooRows[e] - base) / hackSize]++] = e;
+    free(fill);
+    *startOut = start;
+    *listOut = list;
+}
+
+/* hdia.cpp:161-228: hackOffsets[h+1] = hackOffsets[h] + #distinct diagPos. */
+void orc_computeHdiaHackOffsetsFromCoo(int* height, int* hackOffsets, int hackSize, int rows, int cols, int nnz,
+                                       const int* cooRows, const int* cooCols, int base)
+{
+    (void)cols;
+    const int hacks = orc_getHdiaHacksCount(hackSize, rows);
+    int *start, *list;
+    orc_groupByHack(&start, &list, hacks, hackSize, nnz, cooRows, base);
+    orc_keyset set = {0, 0, 0};
+    hackOffsets[0] = 0;
+    for (int h = 0; h < hacks; ++h) {
+        set.count = 0;
+        for (int p = start[h]; p < start[h + 1]; ++p) {
+            const int e = list[p];
+            const int diagId = (cooCols[e] - base) - ((cooRows[e] - base) % hackSize);
+            orc_keyset_insert(&set, hackSize - 1 + diagId);
+        }
+        hackOffsets[h + 1] = hackOffsets[h] + set.count;
+    }
+    *height = hackOffsets[hacks];
+    free(set.key);
+    free(start);
+    free(list);
+}
+
+/* hdia.cpp:230-349: per hack, diagonals in ascending diagPos; offsets entry =
+ * col - row (hdia.cpp:279,300); value slot = row%hackSize + hackSize *
+ * (hackOffsets[h] + position) (hdia.cpp:315-319); later duplicates overwrite. */
+void orc_cooToHdia(void* hdiaVals, int* hdiaOffsets, const int* hackOffsets, int hackSize, int rows, int cols,
+                   int nnz, const int* cooRows, const int* cooCols, const void* cooVals, int base, int type)
+{
+    (void)cols;
+    const size_t es = orc_sizeOf(type);
+    const int hacks = orc_getHdiaHacksCount(hackSize, rows);
+    int *start, *list;
+    orc_groupByHack(&start, &list, hacks, hackSize, nnz, cooRows, base);
+    orc_keyset set = {0, 0, 0};
+    int* global = NULL; /* col - row of each key, first occurrence */
+    int globalCap = 0;
+    for (int h = 0; h < hacks; ++h) {
+        set.count = 0;
+        for (int p = start[h]; p < start[h + 1]; ++p) {
+            const int e = list[p];
+            orc_keyset_insert(&set, hackSize - 1 + (cooCols[e] - base) - ((cooRows[e] - base) % hackSize));
+        }
+        if (set.count > globalCap) {
+            globalCap = set.count;
+            global = (int*)realloc(global, (size_t)globalCap * sizeof(int));
+        }
+        for (int i = 0; i < set.count; ++i)
+            global[i] = 0;
+        /* first entry seen on a diagonal defines its global offset */
+        {
+            char* seen = (char*)calloc(set.count > 0 ? (size_t)set.count : 1, 1);
+            for (int p = start[h]; p < start[h + 1]; ++p) {
+                const int e = list[p];
+                const int pos = orc_keyset_find(&set, hackSize - 1 + (cooCols[e] - base) - ((cooRows[e] - base) % hackSize));
+                if (!seen[pos]) {
+                    seen[pos] = 1;
+                    global[pos] = cooCols[e] - cooRows[e];
+                }
+            }
+            free(seen);
+        }
+        for (int i = 0; i < set.count; ++i)
+            hdiaOffsets[hackOffsets[h] + i] = global[i];
+        for (int p = start[h]; p < start[h + 1]; ++p) {
+            const int e = list[p];
+            const int lane = (cooRows[e] - base) % hackSize;
+            const int pos = orc_keyset_find(&set, hackSize - 1 + (cooCols[e] - base) - lane);
+            const size_t slot = (size_t)lane + (size_t)hackSize * ((size_t)hackOffsets[h] + (size_t)pos);
+            memcpy((char*)hdiaVals + slot * es, (const char*)cooVals + (size_t)e * es, es);
+        }
+    }
+    free(global);
+    free(set.key);
+    free(start);
+    free(list);
+}
+
+/* ======================================================================== */
+/* Arithmetic: hell_spmv_base.cuh:29-51 (real: (a*b)+c contracted to one fma  */
+/* by nvcc's default -fmad; complex: cuCfma / cuCmul).                        */
+/* ======================================================================== */
+typedef struct { float x, y; } orc_cfloat;
+typedef struct { double x, y; } orc_cdouble;
+
+static inline float s_zero(void) { return 0.0f; }
+static inline double d_zero(void) { return 0.0; }
+static inline orc_cfloat c_zero(void) { orc_cfloat r = {0.0f, 0.0f}; return r; }
+static inline orc_cdouble z_zero(void) { orc_cdouble r = {0.0, 0.0}; return r; }
+
+static inline int s_nz(float a) { return a != 0.0f; }
+static inline int d_nz(double a) { return a != 0.0; }
+static inline int c_nz(orc_cfloat a) { return a.x != 0.0f || a.y != 0.0f; }
+static inline int z_nz(orc_cdouble a) { return a.x != 0.0 || a.y != 0.0; }
+
+static inline float s_fma(float a, float b, float c) { return fmaf(a, b, c); }
+static inline double d_fma(double a, double b, double c) { return fma(a, b, c); }
+static inline float s_mul(float a, float b) { return a * b; }
+static inline double d_mul(double a, double b) { return a * b; }
+static inline float s_add(float a, float b) { return a + b; }
+static inline double d_add(double a, double b) { return a + b; }
+
+/* cuCfma: re = (p.x*q.x + r.x) - p.y*q.y ; im = (q.x*p.y + r.y) + p.x*q.y */
+static inline orc_cfloat c_fma(orc_cfloat p, orc_cfloat q, orc_cfloat r)
+{
+    float re = fmaf(p.x, q.x, r.x), im = fmaf(q.x, p.y, r.y);
+    orc_cfloat o = {fmaf(-p.y, q.y, re), fmaf(p.x, q.y, im)};
+    return o;
+}
+static inline orc_cdouble z_fma(orc_cdouble p, orc_cdouble q, orc_cdouble r)
+{
+    double re = fma(p.x, q.x, r.x), im = fma(q.x, p.y, r.y);
+    orc_cdouble o = {fma(-p.y, q.y, re), fma(p.x, q.y, im)};
+    return o;
+}
+/* cuCmul: re = a.x*b.x - a.y*b.y ; im = a.x*b.y + a.y*b.x */
+static inline orc_cfloat c_mul(orc_cfloat a, orc_cfloat b)
+{
+    orc_cfloat o = {fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)};
+    return o;
+}
+static inline orc_cdouble z_mul(orc_cdouble a, orc_cdouble b)
+{
+    orc_cdouble o = {fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)};
+    return o;
+}
+static inline orc_cfloat c_add(orc_cfloat a, orc_cfloat b) { orc_cfloat o = {a.x + b.x, a.y + b.y}; return o; }
+static inline orc_cdouble z_add(orc_cdouble a, orc_cdouble b) { orc_cdouble o = {a.x + b.x, a.y + b.y}; return o; }
+
+static inline float s_abs2acc(float v, float acc) { return fmaf(v, v, acc); }
+static inline double d_abs2acc(double v, double acc) { return fma(v, v, acc); }
+static inline float c_abs2acc(orc_cfloat v, float acc) { return fmaf(v.y, v.y, fmaf(v.x, v.x, acc)); }
+static inline double z_abs2acc(orc_cdouble v, double acc) { return fma(v.y, v.y, fma(v.x, v.x, acc)); }
+
+#define ORC_MAX_PHASES 8
+
+/*
+ * One body for the four value types.
+ *
+ * `phases` selects the order in which the products of one row are added:
+ *   1  ascending k                  -- the reference's one-thread-per-row
+ *                                      kernels (hell_spmv_base_template.cuh:197-214,
+ *                                      ell_spmv_base_template.cuh:178-266)
+ *   2  (even k) + (odd k)           -- the reference's two-threads-per-row
+ *                                      kernels (hell_spmv_base_template.cuh:59-101)
+ *   4,8  k mod phases partial sums, combined pairwise p with p^1, p^2, p^4
+ *                                      -- the MI355X slab kernel's order
+ * Epilogue (hell_spmv_base_template.cuh:219-222):
+ *   beta != 0 : z = fma(beta, y, alpha*sum) ;  beta == 0 : z = alpha*sum, y unread.
+ */
+#define ORC_DEFINE_TYPE(P, T, R)                                                                              \
+    static T P##_combine(T* part, int phases)                                                                 \
+    {                                                                                                         \
+        for (int m = 1; m < phases; m <<= 1) {                                                                \
+            T next[ORC_MAX_PHASES];                                                                           \
+            for (int p = 0; p < phases; ++p)                                                                  \
+                next[p] = P##_add(part[p], part[p ^ m]);                                                      \
+            for (int p = 0; p < phases; ++p)                                                                  \
+                part[p] = next[p];                                                                            \
+        }                                                                                                     \
+        return part[0];                                                                                       \
+    }                                                                                                         \
+                                                                                                              \
+    static void P##_store(T* z, const T* y, int outRow, T alpha, T sum, T beta)                               \
+    {                                                                                                         \
+        if (P##_nz(beta))                                                                                     \
+            z[outRow] = P##_fma(beta, y[outRow], P##_mul(alpha, sum));                                        \
+        else                                                                                                  \
+            z[outRow] = P##_mul(alpha, sum);                                                                  \
+    }                                                                                                         \
+                                                                                                              \
+    /* hell_spmv_base_template.cuh:112-252; rIdx: :227-252 */                                                 \
+    void orc_##P##hellspmv(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,               \
+                           const int* hackOffsets, const int* rS, const int* rIdx, int rows, const T* x,      \
+                           T beta, int baseIndex, int phases)                                                 \
+    {                                                                                                         \
+        _Pragma("omp parallel for schedule(static)")                                                          \
+        for (int i = 0; i < rows; ++i) {                                                                      \
+            const size_t slot0 = (size_t)hackOffsets[i / hackSize] + (size_t)(i % hackSize);                  \
+            T part[ORC_MAX_PHASES];                                                                           \
+            for (int p = 0; p < phases; ++p)                                                                  \
+                part[p] = P##_zero();                                                                         \
+            for (int k = 0; k < rS[i]; ++k) {                                                                 \
+                const size_t s = slot0 + (size_t)k * (size_t)hackSize;                                        \
+                part[k % phases] = P##_fma(cM[s], x[rP[s] - baseIndex], part[k % phases]);                    \
+            }                                                                                                 \
+            P##_store(z, y, rIdx ? rIdx[i] : i, alpha, P##_combine(part, phases), beta);                      \
+        }                                                                                                     \
+    }                                                                                                         \
+                                                                                                              \
+    /* ell_spmv_base_template.cuh:102-266, ell_spmv_base_nors.cuh:97-258 (rS == NULL) */                     \
+    void orc_##P##ellspmv(T* z, const T* y, T alpha, const T* cM, const int* rP, int cMPitch, int rPPitch,    \
+                          const int* rS, const int* rIdx, int maxNnzPerRow, int rows, const T* x, T beta,     \
+                          int baseIndex, int phases)                                                          \
+    {                                                                                                         \
+        _Pragma("omp parallel for schedule(static)")                                                          \
+        for (int i = 0; i < rows; ++i) {                                                                      \
+            const int len = rS ? rS[i] : maxNnzPerRow;                                                        \
+            T part[ORC_MAX_PHASES];                                                                           \
+            for (int p = 0; p < phases; ++p)                                                                  \
+                part[p] = P##_zero();                                                                         \
+            for (int k = 0; k < len; ++k) {                                                                   \
+                const int col = rP[(size_t)i + (size_t)k * (size_t)rPPitch] - baseIndex;                      \
+                if (col < 0)                                                                                  \
+                    continue; /* zero padding with baseIndex 1: the reference reads x[-1] here */            \
+                part[k % phases] = P##_fma(cM[(size_t)i + (size_t)k * (size_t)cMPitch], x[col], part[k % phases]); \
+            }                                                                                                 \
+            P##_store(z, y, rIdx ? rIdx[i] : i, alpha, P##_combine(part, phases), beta);                      \
+        }                                                                                                     \
+    }                                                                                                         \
+                                                                                                              \
+    /* hdia_spmv_base_template.cuh:19-206: diagonals of the row's hack in stored order, */                    \
+    /* a slot counts iff 0 <= offsets[d] + i < cols (:111-118). */                                            \
+    void orc_##P##hdiaspmv(T* z, const T* y, T alpha, const T* dM, const int* offsets, int hackSize,          \
+                           const int* hackOffsets, int rows, int cols, const T* x, T beta)                    \
+    {                                                                                                         \
+        _Pragma("omp parallel for schedule(static)")                                                          \
+        for (int i = 0; i < rows; ++i) {                                                                      \
+            const int h = i / hackSize, lane = i % hackSize;                                                  \
+            T sum = P##_zero();                                                                               \
+            for (int d = hackOffsets[h]; d < hackOffsets[h + 1]; ++d) {                                       \
+                const long long col = (long long)offsets[d] + i;                                              \
+                if (col >= 0 && col < cols)                                                                   \
+                    sum = P##_fma(dM[(size_t)d * (size_t)hackSize + (size_t)lane], x[col], sum);              \
+            }                                                                                                 \
+            P##_store(z, y, i, alpha, sum, beta);                                                             \
+        }                                                                                                     \
+    }                                                                                                         \
+                                                                                                              \
+    /* ddot.cu:37-150 (plain, un-conjugated sum; zdot.cu:54).  The reference's order of */                    \
+    /* addition depends on its launch geometry; this oracle adds in ascending i. */                           \
+    void orc_##P##dot(T* out, int n, const T* a, const T* b)                                                  \
+    {                                                                                                         \
+        T acc = P##_zero();                                                                                   \
+        for (int i = 0; i < n; ++i)                                                                           \
+            acc = P##_fma(a[i], b[i], acc);                                                                   \
+        *out = acc;                                                                                           \
+    }                                                                                                         \
+                                                                                                              \
+    /* dnrm2.cu:52-53,146: sqrt of the unscaled sum of squares. */                                            \
+    void orc_##P##nrm2(R* out, int n, const T* a)                                                             \
+    {                                                                                                         \
+        R acc = 0;                                                                                            \
+        for (int i = 0; i < n; ++i)                                                                           \
+            acc = P##_abs2acc(a[i], acc);                                                                     \
+        *out = (R)sqrt((double)acc);                                                                          \
+    }
+
+ORC_DEFINE_TYPE(s, float, float)
+ORC_DEFINE_TYPE(d, double, double)
+ORC_DEFINE_TYPE(c, orc_cfloat, float)
+ORC_DEFINE_TYPE(z, orc_cdouble, double)
+
+/* axpby: daxpby.cu:31-45 (alpha*x + beta*y, contracted as fma(alpha, x, beta*y));
+ * caxpby.cu:41-44 (fma(beta, y, alpha*x)); zaxpby.cu:42-45 (fma(alpha, x, beta*y)).
+ * beta == 0: z = alpha*x, y unread. */
+void orc_saxpby(float* z, int n, float beta, const float* y, float alpha, const float* x)
+{
+    for (int i = 0; i < n; ++i)
+        z[i] = beta == 0.0f ? alpha * x[i] : fmaf(alpha, x[i], beta * y[i]);
+}
+void orc_daxpby(double* z, int n, double beta, const double* y, double alpha, const double* x)
+{
+    for (int i = 0; i < n; ++i)
+        z[i] = beta == 0.0 ? alpha * x[i] : fma(alpha, x[i], beta * y[i]);
+}
+void orc_caxpby(orc_cfloat* z, int n, orc_cfloat beta, const orc_cfloat* y, orc_cfloat alpha, const orc_cfloat* x)
+{
+    for (int i = 0; i < n; ++i)
+        z[i] = c_nz(beta) ? c_fma(beta, y[i], c_mul(alpha, x[i])) : c_mul(alpha, x[i]);
+}
+void orc_zaxpby(orc_cdouble* z, int n, orc_cdouble beta, const orc_cdouble* y, orc_cdouble alpha, const orc_cdouble* x)
+{
+    for (int i = 0; i < n; ++i)
+        z[i] = z_nz(beta) ? z_fma(alpha, x[i], z_mul(beta, y[i])) : z_mul(alpha, x[i]);
+}
+
+/* Multi-vector SpMM oracle for the row-sharded path (new; not in the
+ * reference): column j of X/Y/Z is an independent HELL SpMV, vector j at
+ * base + j*pitch (the reference's multivector convention, vector.h:75-91). */
+void orc_dhellspmm(double* Z, const double* Y, double alpha, const double* cM, const int* rP, int hackSize,
+                   const int* hackOffsets, const int* rS, const int* rIdx, int rows, const double* X, double beta,
+                   int baseIndex, int count, int xPitch, int yzPitch, int phases)
+{
+    for (int j = 0; j < count; ++j)
+        orc_dhellspmv(Z + (size_t)j * yzPitch, Y ? Y + (size_t)j * yzPitch : NULL, alpha, cM, rP, hackSize, hackOffsets,
+                      rS, rIdx, rows, X + (size_t)j * xPitch, beta, baseIndex, phases);
+}

@@ -1,0 +1,125 @@
+"""ctypes bindings of the spgpu-amd C ABI (``include/spgpu/*.h``).
+
+Every entry point is bound with its exact C signature; nothing here computes.
+Device arrays are passed as raw addresses (``tensor.data_ptr()``), scalars by
+value, exactly like a C caller of the reference would (``hell.h:45-59``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspgpu.so")
+
+
+class MissingNativeLibrary(ImportError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise MissingNativeLibrary(
+        f"{LIB_PATH} not found: build it with `make lib` (or __graft_entry__.build()); "
+        "spgpu-amd has no Python or CPU fallback for its kernels")
+
+lib = C.CDLL(LIB_PATH)
+
+# ---- types ------------------------------------------------------------------
+SPGPU_SUCCESS, SPGPU_UNSUPPORTED, SPGPU_UNSPECIFIED, SPGPU_OUTOFMEMORY = 0, 1, 2, 3
+TYPE_INT, TYPE_FLOAT, TYPE_DOUBLE, TYPE_COMPLEX_FLOAT, TYPE_COMPLEX_DOUBLE = range(5)
+
+
+class FloatComplex(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class DoubleComplex(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double)]
+
+
+class HandleStruct(C.Structure):
+    """Public fields of SpgpuHandleStruct (include/spgpu/core.h; reference core.h:60-82)."""
+    _fields_ = [
+        ("currentStream", C.c_void_p), ("defaultStream", C.c_void_p),
+        ("device", C.c_int), ("warpSize", C.c_int), ("maxThreadsPerBlock", C.c_int),
+        ("maxGridSizeX", C.c_int), ("maxGridSizeY", C.c_int), ("maxGridSizeZ", C.c_int),
+        ("multiProcessorCount", C.c_int), ("capabilityMajor", C.c_int), ("capabilityMinor", C.c_int),
+    ]
+
+
+Handle = C.POINTER(HandleStruct)
+ptr = C.c_void_p  # device or host address
+i32 = C.c_int
+
+# scalar C type per letter of the API
+SCALAR = {"S": C.c_float, "D": C.c_double, "C": FloatComplex, "Z": DoubleComplex}
+REAL = {"S": C.c_float, "D": C.c_double, "C": C.c_float, "Z": C.c_double}
+TYPE_CODE = {"S": TYPE_FLOAT, "D": TYPE_DOUBLE, "C": TYPE_COMPLEX_FLOAT, "Z": TYPE_COMPLEX_DOUBLE}
+
+
+def scalar(letter, value):
+    """Python number -> the by-value C scalar of the given API flavour."""
+    if letter in "SD":
+        return SCALAR[letter](float(value))
+    v = complex(value)
+    return SCALAR[letter](v.real, v.imag)
+
+
+def _bind(name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+DECLARED = {}  # name -> (restype, argtypes); the test suite checks it against the headers
+
+
+def _decl(name, restype, argtypes):
+    DECLARED[name] = (restype, argtypes)
+    return _bind(name, restype, argtypes)
+
+
+# ---- core.h -------------------------------------------------------------------
+spgpuCreate = _decl("spgpuCreate", i32, [C.POINTER(Handle), i32])
+spgpuDestroy = _decl("spgpuDestroy", None, [Handle])
+spgpuStreamCreate = _decl("spgpuStreamCreate", None, [Handle, C.POINTER(C.c_void_p)])
+spgpuStreamDestroy = _decl("spgpuStreamDestroy", None, [C.c_void_p])
+spgpuSetStream = _decl("spgpuSetStream", None, [Handle, C.c_void_p])
+spgpuGetStream = _decl("spgpuGetStream", C.c_void_p, [Handle])
+spgpuSizeOf = _decl("spgpuSizeOf", C.c_size_t, [i32])
+
+# ---- hell.h / ell.h / hdia.h ----------------------------------------------------
+hellspmv, ellspmv, hdiaspmv = {}, {}, {}
+axpby, maxpby, dot, mdot, nrm2, mnrm2 = {}, {}, {}, {}, {}, {}
+for _L, _T in SCALAR.items():
+    hellspmv[_L] = _decl(f"spgpu{_L}hellspmv", None,
+                         [Handle, ptr, ptr, _T, ptr, ptr, i32, ptr, ptr, ptr, i32, i32, ptr, _T, i32])
+    ellspmv[_L] = _decl(f"spgpu{_L}ellspmv", None,
+                        [Handle, ptr, ptr, _T, ptr, ptr, i32, i32, ptr, ptr, i32, i32, i32, ptr, _T, i32])
+    hdiaspmv[_L] = _decl(f"spgpu{_L}hdiaspmv", None,
+                         [Handle, ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, _T])
+    # ---- vector.h ---------------------------------------------------------------
+    axpby[_L] = _decl(f"spgpu{_L}axpby", None, [Handle, ptr, i32, _T, ptr, _T, ptr])
+    maxpby[_L] = _decl(f"spgpu{_L}maxpby", None, [Handle, ptr, i32, _T, ptr, _T, ptr, i32, i32])
+    dot[_L] = _decl(f"spgpu{_L}dot", _T, [Handle, i32, ptr, ptr])
+    mdot[_L] = _decl(f"spgpu{_L}mdot", None, [Handle, ptr, i32, ptr, ptr, i32, i32])
+    nrm2[_L] = _decl(f"spgpu{_L}nrm2", REAL[_L], [Handle, i32, ptr])
+    mnrm2[_L] = _decl(f"spgpu{_L}mnrm2", None, [Handle, ptr, i32, ptr, i32, i32])
+
+# ---- ell_conv.h / hell_conv.h / hdia_conv.h (host pointers) --------------------------
+computeEllRowLenghts = _decl("computeEllRowLenghts", None, [ptr, C.POINTER(i32), i32, i32, ptr, i32])
+computeEllAllocPitch = _decl("computeEllAllocPitch", i32, [i32])
+cooToEll = _decl("cooToEll", None, [ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32])
+computeHellAllocSize = _decl("computeHellAllocSize", None, [C.POINTER(i32), i32, i32, ptr])
+ellToHell = _decl("ellToHell", None, [ptr, ptr, ptr, i32, ptr, ptr, i32, i32, ptr, i32, i32])
+getHdiaHacksCount = _decl("getHdiaHacksCount", i32, [i32, i32])
+computeHdiaHackOffsetsFromCoo = _decl("computeHdiaHackOffsetsFromCoo", None,
+                                      [C.POINTER(i32), ptr, i32, i32, i32, i32, ptr, ptr, i32])
+cooToHdia = _decl("cooToHdia", None, [ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32])
+
+
+def create_handle(device=0):
+    h = Handle()
+    status = spgpuCreate(C.byref(h), device)
+    if status != SPGPU_SUCCESS or not h:
+        raise RuntimeError(f"spgpuCreate(device={device}) failed with status {status}")
+    return h

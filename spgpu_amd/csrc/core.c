@@ -1,0 +1,113 @@
+/*
+ * Handle / runtime layer of the spgpu-amd C ABI (include/spgpu/core.h).
+ * Behavioural model: reference src/core/core.c:11-99.  Written for HIP on
+ * MI355X; the handle additionally owns the scratch that the reductions use
+ * (the reference keeps that in a process-global __device__ array,
+ * kernels/ddot.cu:35).
+ */
+#include "spgpu_internal.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
+{
+    if (!pHandle)
+        return SPGPU_UNSPECIFIED;
+    *pHandle = NULL;
+
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return SPGPU_UNSPECIFIED;
+
+    SpgpuPrivateHandle* h = (SpgpuPrivateHandle*)calloc(1, sizeof(SpgpuPrivateHandle));
+    if (!h)
+        return SPGPU_OUTOFMEMORY;
+
+    int previous = 0;
+    hipGetDevice(&previous);
+    hipError_t err = hipSetDevice(device);
+    if (err == hipSuccess)
+        err = hipStreamCreate(&h->pub.defaultStream);
+    if (err == hipSuccess)
+        err = hipMalloc(&h->reduceScratch, SPGPU_REDUCE_SCRATCH_BYTES);
+    if (err == hipSuccess)
+        err = hipHostMalloc(&h->reduceHost, SPGPU_REDUCE_SCRATCH_BYTES, hipHostMallocDefault);
+    hipSetDevice(previous);
+
+    if (err != hipSuccess) {
+        if (h->reduceScratch) hipFree(h->reduceScratch);
+        if (h->pub.defaultStream) hipStreamDestroy(h->pub.defaultStream);
+        free(h);
+        return err == hipErrorOutOfMemory ? SPGPU_OUTOFMEMORY : SPGPU_UNSPECIFIED;
+    }
+
+    h->pub.currentStream = h->pub.defaultStream;
+    h->pub.device = device;
+    h->pub.warpSize = prop.warpSize;
+    h->pub.maxThreadsPerBlock = prop.maxThreadsPerBlock;
+    h->pub.maxGridSizeX = prop.maxGridSize[0];
+    h->pub.maxGridSizeY = prop.maxGridSize[1];
+    h->pub.maxGridSizeZ = prop.maxGridSize[2];
+    h->pub.multiProcessorCount = prop.multiProcessorCount;
+    h->pub.capabilityMajor = prop.major;
+    h->pub.capabilityMinor = prop.minor;
+    h->magic = SPGPU_HANDLE_MAGIC;
+
+    *pHandle = &h->pub;
+    return SPGPU_SUCCESS;
+}
+
+void spgpuDestroy(spgpuHandle_t pHandle)
+{
+    if (!pHandle)
+        return;
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    int previous = 0;
+    hipGetDevice(&previous);
+    hipSetDevice(h->pub.device);
+    hipStreamSynchronize(h->pub.defaultStream);
+    hipFree(h->reduceScratch);
+    hipHostFree(h->reduceHost);
+    hipStreamDestroy(h->pub.defaultStream);
+    hipSetDevice(previous);
+    h->magic = 0;
+    free(h);
+}
+
+void spgpuStreamCreate(spgpuHandle_t pHandle, hipStream_t* stream)
+{
+    int previous = 0;
+    hipGetDevice(&previous);
+    hipSetDevice(pHandle->device);
+    hipStreamCreate(stream);
+    hipSetDevice(previous);
+}
+
+void spgpuStreamDestroy(hipStream_t stream)
+{
+    hipStreamDestroy(stream);
+}
+
+void spgpuSetStream(spgpuHandle_t pHandle, hipStream_t stream)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    h->pub.currentStream = stream ? stream : h->pub.defaultStream;
+}
+
+hipStream_t spgpuGetStream(spgpuHandle_t pHandle)
+{
+    return pHandle->currentStream;
+}
+
+size_t spgpuSizeOf(spgpuType_t typeCode)
+{
+    switch (typeCode) {
+    case SPGPU_TYPE_INT:            return sizeof(int);
+    case SPGPU_TYPE_FLOAT:          return sizeof(float);
+    case SPGPU_TYPE_DOUBLE:         return sizeof(double);
+    case SPGPU_TYPE_COMPLEX_FLOAT:  return sizeof(hipFloatComplex);
+    case SPGPU_TYPE_COMPLEX_DOUBLE: return sizeof(hipDoubleComplex);
+    default:                        return 0;
+    }
+}

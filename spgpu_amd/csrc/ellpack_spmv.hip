@@ -1,0 +1,433 @@
+/*
+ * ELL and HELL SpMV for gfx950 (MI355X):  z = alpha*A*x + beta*y.
+ *
+ * C ABI: spgpu{S,D,C,Z}hellspmv (include/spgpu/hell.h, reference hell.h:45-169)
+ *        spgpu{S,D,C,Z}ellspmv  (include/spgpu/ell.h,  reference ell.h:46-173)
+ * Behaviour follows the reference dispatchers/kernels
+ * (kernels/hell_spmv_base.cuh:103-157, hell_spmv_base_template.cuh:19-357,
+ *  kernels/ell_spmv_base.cuh:99-146, ell_spmv_base_template.cuh:102-425,
+ *  ell_spmv_base_nors.cuh:17-340); the kernel design below is new.
+ *
+ * ---- Wavefront design ("slab" kernel) ------------------------------------
+ * Both formats store a block of 32 consecutive rows as a column-major slab:
+ * element (row r, k-th entry) sits at  slabBase + r%32 + k*stride  with
+ * stride = hackSize (HELL) or the pitch (ELL).  One 64-lane wavefront owns
+ * one such 32-row group (for hackSize == 32: exactly one hack).
+ *
+ *   RPL   = rows per lane = 16 B / sizeof(T)  (S:4  D:2  C:2  Z:1)
+ *   LPC   = 32 / RPL lanes cover one slab column with one 16-B load each
+ *   PH    = 64 / LPC = 2*RPL "phases": lane group p handles entries k = p, p+PH, ...
+ *
+ * A wave-wide load therefore moves PH slab columns at once: 1 KiB of
+ * coefficients (global_load_dwordx4 per lane) plus the matching indices,
+ * and for hackSize == 32 those PH columns are contiguous in memory, so the
+ * wave streams the hack front to back in 1-KiB pieces.  Each lane gathers
+ * x for its RPL rows, keeps RPL running sums, and the PH partial sums of a
+ * row are combined with log2(PH) lane-xor shuffles (DPP / ds_bpermute; no LDS,
+ * no barrier).  Lanes of phase 0 apply alpha/beta and write RPL consecutive z
+ * values with one wide store.
+ *
+ * Summation order of one row: entries k = p (mod PH) are accumulated in
+ * ascending k per phase p, then phases are added pairwise (xor tree).  For
+ * PH == 2 (double complex) this is exactly the reference's two-threads-per-row
+ * order (hell_spmv_base_template.cuh:59-101).
+ *
+ * The same kernel template with RPL == 1 (element loads) and/or PH == 1 (a
+ * lane walks whole rows) takes the cases the wide form cannot: streams that
+ * are not 16-byte aligned, odd pitches, hackSize not a multiple of RPL
+ * (every lane derives its hack from its own first row, so any hackSize works).
+ *
+ * Roofline: HBM bandwidth.  Algorithmic bytes per nonzero: sizeof(T) + 4;
+ * per row: 4 (rS) + sizeof(T) (z) [+ sizeof(T) for y when beta != 0]
+ * [+ 4 for rIdx]; per column: sizeof(T) (x once); per hack: 4.
+ */
+#include "numeric.hip.h"
+#include "spgpu_internal.h"
+
+#include "spgpu/ell.h"
+#include "spgpu/hell.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace spgpu {
+
+template <typename T> struct SlabArgs {
+    T* z;
+    const T* y;
+    const T* x;
+    const T* cM;
+    const int* rP;
+    const int* rS;          /* NULL: every row has maxNnz slots (ELL only) */
+    const int* rIdx;        /* NULL: identity */
+    const int* hackOffsets; /* HELL only */
+    T alpha, beta;
+    int rows;
+    int baseIndex;
+    int hackSize; /* HELL only */
+    int maxNnz;   /* ELL without rS */
+    long long valStride, idxStride; /* elements between two slab columns */
+    int wideIO;   /* y and z are aligned for RPL-wide access */
+};
+
+constexpr int kBlockThreads = 256;
+constexpr int kWavesPerBlock = kBlockThreads / kWave;
+
+/*
+ * RPL    rows per lane (1, or 16/sizeof(T) with 16-byte loads)
+ * PH     phases: lane groups that split the entries of a row by k mod PH
+ *        (PH == 1: a lane walks all entries of its rows, no cross-lane sum)
+ * UNROLL slab-column loads issued back to back before the first gather
+ * One wavefront owns 64/PH strips = (64/PH)*RPL consecutive rows.
+ */
+template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL>
+__global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T> a)
+{
+    constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
+    constexpr int GROUP_ROWS = LPC * RPL;   /* rows owned by the wavefront */
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long group = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long groupRow0 = group * GROUP_ROWS;
+    if (groupRow0 >= a.rows)
+        return; /* whole wavefront leaves together */
+
+    const int sub = lane % LPC;   /* which RPL-row strip of the group */
+    const int phase = lane / LPC; /* which residue class of k */
+    const long long row0 = groupRow0 + (long long)sub * RPL;
+    const bool stripLive = row0 < a.rows;
+
+    /* First slot of this lane's strip, in elements. */
+    long long slab = 0;
+    if (stripLive) {
+        if constexpr (IS_HELL) {
+            const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
+            const unsigned hack = r0 / hs;
+            slab = (long long)a.hackOffsets[hack] + (r0 - hack * hs);
+        } else {
+            slab = row0;
+        }
+    }
+
+    int len[RPL];
+    int laneLongest = 0;
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) {
+        const long long r = row0 + t;
+        len[t] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+        laneLongest = len[t] > laneLongest ? len[t] : laneLongest;
+    }
+    const int groupLongest = waveMax(laneLongest); /* wave-uniform trip count */
+
+    T sum[RPL];
+#pragma unroll
+    for (int t = 0; t < RPL; ++t)
+        sum[t] = zeroOf<T>();
+
+    const T* __restrict__ vals = a.cM + slab;
+    const int* __restrict__ idxs = a.rP + slab;
+    const T* __restrict__ x = a.x;
+
+    for (int kBase = 0; kBase < groupLongest; kBase += PH * UNROLL) {
+        Pack<T, RPL> v[UNROLL];
+        Pack<int, RPL> c[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = kBase + u * PH + phase;
+            if (k < laneLongest) {
+                v[u] = loadPack<NT, T, RPL>(vals + (long long)k * a.valStride);
+                c[u] = loadPack<NT, int, RPL>(idxs + (long long)k * a.idxStride);
+            } else {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    v[u].v[t] = zeroOf<T>();
+                    c[u].v[t] = a.baseIndex;
+                }
+            }
+        }
+        T xv[UNROLL][RPL];
+        bool use[UNROLL][RPL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = kBase + u * PH + phase;
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                const int col = c[u].v[t] - a.baseIndex;
+                use[u][t] = k < len[t] && col >= 0;
+                xv[u][t] = x[use[u][t] ? col : 0];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                const T next = mulAdd(v[u].v[t], xv[u][t], sum[t]);
+                sum[t] = use[u][t] ? next : sum[t];
+            }
+        }
+    }
+
+    /* Combine the PH phase partials of every row. */
+#pragma unroll
+    for (int m = LPC; m < kWave; m <<= 1) {
+#pragma unroll
+        for (int t = 0; t < RPL; ++t)
+            sum[t] = add(sum[t], laneXor(sum[t], m));
+    }
+
+    if (phase != 0 || !stripLive)
+        return;
+
+    const bool hasBeta = isNotZero(a.beta);
+    if (!a.rIdx && a.wideIO && row0 + RPL <= a.rows) {
+        Pack<T, RPL> out;
+        if (hasBeta) {
+            const Pack<T, RPL> yv = loadPack<false, T, RPL>(a.y + row0);
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                out.v[t] = epilogue<true>(a.alpha, sum[t], a.beta, yv.v[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                out.v[t] = epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
+        }
+        storePack<T, RPL>(a.z + row0, out);
+    } else {
+#pragma unroll
+        for (int t = 0; t < RPL; ++t) {
+            const long long r = row0 + t;
+            if (r < a.rows) {
+                const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+                a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
+                                      : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
+            }
+        }
+    }
+}
+
+/* ---- host side ----------------------------------------------------------- */
+
+static int envInt(const char* name, int fallback)
+{
+    const char* s = getenv(name);
+    return s && *s ? atoi(s) : fallback;
+}
+
+static bool alignedTo(const void* p, size_t bytes)
+{
+    return ((uintptr_t)p % bytes) == 0;
+}
+
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL>
+static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
+{
+    constexpr int GROUP_ROWS = (kWave / PH) * RPL;
+    const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
+    const unsigned blocks = (unsigned)((groups + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (nt)
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL>), dim3(blocks),
+                           dim3(kBlockThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL>), dim3(blocks),
+                           dim3(kBlockThreads), 0, stream, a);
+}
+
+template <typename T, bool IS_HELL>
+static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
+{
+    if (in.rows <= 0)
+        return;
+    SlabArgs<T> a = in;
+    hipStream_t stream = handle->currentStream;
+
+    constexpr int WIDE = 16 / (int)sizeof(T);
+    /* A lane reads WIDE consecutive rows of a slab column with one 16-byte
+     * load: the strip must not straddle a hack (HELL) or run past the pitch
+     * (ELL), and the streams must be 16-byte aligned. */
+    const long long stripRows = ((long long)a.rows + WIDE - 1) / WIDE * WIDE;
+    const bool layoutOk = IS_HELL ? (a.hackSize > 0 && a.hackSize % WIDE == 0)
+                                  : (a.valStride >= stripRows && a.idxStride >= stripRows);
+    const bool wideOk = layoutOk && alignedTo(a.cM, 16) && alignedTo(a.rP, 4 * WIDE) &&
+                        a.valStride % WIDE == 0 && a.idxStride % WIDE == 0;
+
+    /* Tuning knobs (experiments only): SPGPU_SPMV_VARIANT
+     *   0 auto | 1 wide+phases | 2 wide, one lane per strip | 3 narrow+2 phases | 4 narrow, lane per row
+     * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams. */
+    int variant = envInt("SPGPU_SPMV_VARIANT", 0);
+    const bool nt = envInt("SPGPU_NT_LOADS", 1) != 0;
+    if (variant < 1 || variant > 4)
+        variant = wideOk ? 1 : 3;
+    if (!wideOk && variant <= 2)
+        variant += 2;
+
+    if (variant <= 2) {
+        a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
+        if constexpr (WIDE > 1) {
+            if (variant == 1)
+                launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2>(stream, a, nt);
+            else
+                launchSlab<T, WIDE, 1, IS_HELL, 4>(stream, a, nt);
+            return;
+        }
+    }
+    a.wideIO = 1; /* RPL == 1: element access is always aligned */
+    if (variant == 1 || variant == 3)
+        launchSlab<T, 1, 2, IS_HELL, 4>(stream, a, nt);
+    else
+        launchSlab<T, 1, 1, IS_HELL, 4>(stream, a, nt);
+}
+
+template <typename T, typename ApiT>
+static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, const ApiT* cM, const int* rP,
+                     int hackSize, const int* hackOffsets, const int* rS, const int* rIdx, int rows,
+                     const ApiT* x, ApiT beta, int baseIndex)
+{
+    static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
+    SlabArgs<T> a;
+    a.z = reinterpret_cast<T*>(z);
+    a.y = reinterpret_cast<const T*>(y);
+    a.x = reinterpret_cast<const T*>(x);
+    a.cM = reinterpret_cast<const T*>(cM);
+    a.rP = rP;
+    a.rS = rS;
+    a.rIdx = rIdx;
+    a.hackOffsets = hackOffsets;
+    __builtin_memcpy(&a.alpha, &alpha, sizeof(T));
+    __builtin_memcpy(&a.beta, &beta, sizeof(T));
+    a.rows = rows;
+    a.baseIndex = baseIndex;
+    a.hackSize = hackSize;
+    a.maxNnz = 0;
+    a.valStride = hackSize;
+    a.idxStride = hackSize;
+    a.wideIO = 0;
+    launchSlabFamily<T, true>(handle, a);
+    spgpuDebugCheck(handle, "hellspmv");
+}
+
+template <typename T, typename ApiT>
+static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, const ApiT* cM, const int* rP,
+                    int cMPitch, int rPPitch, const int* rS, const int* rIdx, int maxNnzPerRow, int rows,
+                    const ApiT* x, ApiT beta, int baseIndex)
+{
+    static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
+    SlabArgs<T> a;
+    a.z = reinterpret_cast<T*>(z);
+    a.y = reinterpret_cast<const T*>(y);
+    a.x = reinterpret_cast<const T*>(x);
+    a.cM = reinterpret_cast<const T*>(cM);
+    a.rP = rP;
+    a.rS = rS;
+    a.rIdx = rIdx;
+    a.hackOffsets = nullptr;
+    __builtin_memcpy(&a.alpha, &alpha, sizeof(T));
+    __builtin_memcpy(&a.beta, &beta, sizeof(T));
+    a.rows = rows;
+    a.baseIndex = baseIndex;
+    a.hackSize = 0;
+    a.maxNnz = maxNnzPerRow;
+    a.valStride = cMPitch;
+    a.idxStride = rPPitch;
+    a.wideIO = 0;
+    launchSlabFamily<T, false>(handle, a);
+    spgpuDebugCheck(handle, "ellspmv");
+}
+
+} // namespace spgpu
+
+using namespace spgpu;
+
+extern "C" {
+
+void spgpuDebugCheck(spgpuHandle_t h, const char* what)
+{
+#ifdef SPGPU_DEBUG
+    hipError_t err = hipStreamSynchronize(h->currentStream);
+    if (err == hipSuccess)
+        err = hipGetLastError();
+    if (err != hipSuccess) {
+        fprintf(stderr, "spgpu: HIP error in %s: %s\n", what, hipGetErrorString(err));
+        exit(1);
+    }
+#else
+    (void)h;
+    (void)what;
+#endif
+}
+
+/* avgNnzPerRow is a tuning hint in the reference (threads-per-row choice,
+ * hell_spmv_base_template.cuh:306-325); the slab kernel does not need it. */
+
+void spgpuShellspmv(spgpuHandle_t handle, float* z, const float* y, float alpha, const float* cM,
+                    const int* rP, int hackSize, const int* hackOffsets, const int* rS, const int* rIdx,
+                    int avgNnzPerRow, int rows, const float* x, float beta, int baseIndex)
+{
+    (void)avgNnzPerRow;
+    hellSpmv<float>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex);
+}
+
+void spgpuDhellspmv(spgpuHandle_t handle, double* z, const double* y, double alpha, const double* cM,
+                    const int* rP, int hackSize, const int* hackOffsets, const int* rS, const int* rIdx,
+                    int avgNnzPerRow, int rows, const double* x, double beta, int baseIndex)
+{
+    (void)avgNnzPerRow;
+    hellSpmv<double>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex);
+}
+
+void spgpuChellspmv(spgpuHandle_t handle, hipFloatComplex* z, const hipFloatComplex* y, hipFloatComplex alpha,
+                    const hipFloatComplex* cM, const int* rP, int hackSize, const int* hackOffsets,
+                    const int* rS, const int* rIdx, int avgNnzPerRow, int rows, const hipFloatComplex* x,
+                    hipFloatComplex beta, int baseIndex)
+{
+    (void)avgNnzPerRow;
+    hellSpmv<cfloat>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex);
+}
+
+void spgpuZhellspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleComplex* y,
+                    hipDoubleComplex alpha, const hipDoubleComplex* cM, const int* rP, int hackSize,
+                    const int* hackOffsets, const int* rS, const int* rIdx, int avgNnzPerRow, int rows,
+                    const hipDoubleComplex* x, hipDoubleComplex beta, int baseIndex)
+{
+    (void)avgNnzPerRow;
+    hellSpmv<cdouble>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex);
+}
+
+void spgpuSellspmv(spgpuHandle_t handle, float* z, const float* y, float alpha, const float* cM, const int* rP,
+                   int cMPitch, int rPPitch, const int* rS, const int* rIdx, int avgNnzPerRow,
+                   int maxNnzPerRow, int rows, const float* x, float beta, int baseIndex)
+{
+    (void)avgNnzPerRow;
+    ellSpmv<float>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
+                   baseIndex);
+}
+
+void spgpuDellspmv(spgpuHandle_t handle, double* z, const double* y, double alpha, const double* cM,
+                   const int* rP, int cMPitch, int rPPitch, const int* rS, const int* rIdx, int avgNnzPerRow,
+                   int maxNnzPerRow, int rows, const double* x, double beta, int baseIndex)
+{
+    (void)avgNnzPerRow;
+    ellSpmv<double>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
+                    baseIndex);
+}
+
+void spgpuCellspmv(spgpuHandle_t handle, hipFloatComplex* z, const hipFloatComplex* y, hipFloatComplex alpha,
+                   const hipFloatComplex* cM, const int* rP, int cMPitch, int rPPitch, const int* rS,
+                   const int* rIdx, int avgNnzPerRow, int maxNnzPerRow, int rows, const hipFloatComplex* x,
+                   hipFloatComplex beta, int baseIndex)
+{
+    (void)avgNnzPerRow;
+    ellSpmv<cfloat>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
+                    baseIndex);
+}
+
+void spgpuZellspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleComplex* y, hipDoubleComplex alpha,
+                   const hipDoubleComplex* cM, const int* rP, int cMPitch, int rPPitch, const int* rS,
+                   const int* rIdx, int avgNnzPerRow, int maxNnzPerRow, int rows, const hipDoubleComplex* x,
+                   hipDoubleComplex beta, int baseIndex)
+{
+    (void)avgNnzPerRow;
+    ellSpmv<cdouble>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
+                     baseIndex);
+}
+
+} // extern "C"

@@ -1,0 +1,236 @@
+/*
+ * HDIA (sliced diagonal) SpMV for gfx950 (MI355X):  z = alpha*A*x + beta*y.
+ *
+ * C ABI: spgpu{S,D,C,Z}hdiaspmv (include/spgpu/hdia.h, reference hdia.h:37-142).
+ * Behaviour follows the reference dispatcher/kernel
+ * (kernels/hdia_spmv_base.cuh:99-145, hdia_spmv_base_template.cuh:19-252):
+ * a stored slot (hack-local diagonal d, row r) contributes iff
+ * 0 <= offsets[d] + r < cols; products of a row are added in ascending d.
+ * The kernel design below is new.
+ *
+ * ---- Wavefront design -------------------------------------------------------
+ * A hack's coefficients are one contiguous block, diagonal after diagonal,
+ * hackSize rows each, and consecutive hacks follow each other in memory.  A
+ * lane owns a strip of RPL = 16 B / sizeof(T) consecutive rows (one 16-byte
+ * load per stored diagonal), a wavefront owns 64*RPL consecutive rows (for
+ * double and hackSize 32: four whole hacks, i.e. one contiguous piece of dM).
+ * Diagonal counts per hack are small (7 for a 3-D Laplacian), so a lane walks
+ * all diagonals of its strip itself: no cross-lane reduction, no LDS, no
+ * barrier, and the summation order per row equals the reference's.
+ * The diagonal offsets of a hack are read with one load per diagonal that is
+ * the same address for all lanes of the strip's hack (a broadcast out of L1);
+ * x is read at offsets[d] + row, i.e. contiguously across the lanes of a hack.
+ * UNROLL diagonals are in flight per lane before the first multiply-add.
+ *
+ * Roofline: HBM bandwidth.  Algorithmic bytes: sizeof(T) per stored in-range
+ * slot, 4 per stored diagonal, 4 per hack (+4), sizeof(T) per column (x once)
+ * and per row (z) [+ y when beta != 0].
+ */
+#include "numeric.hip.h"
+#include "spgpu_internal.h"
+
+#include "spgpu/hdia.h"
+
+#include <stdlib.h>
+
+namespace spgpu {
+
+template <typename T> struct HdiaArgs {
+    T* z;
+    const T* y;
+    const T* x;
+    const T* dM;
+    const int* offsets;
+    const int* hackOffsets;
+    T alpha, beta;
+    int rows, cols, hackSize;
+    int wideIO;
+};
+
+constexpr int kHdiaThreads = 256;
+
+template <typename T, int RPL, bool NT, int UNROLL>
+__global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T> a)
+{
+    const long long strip = (long long)blockIdx.x * kHdiaThreads + threadIdx.x;
+    const long long waveRow0 = (strip - (threadIdx.x & (kWave - 1))) * RPL;
+    if (waveRow0 >= a.rows)
+        return; /* whole wavefront leaves together */
+
+    const long long row0 = strip * RPL;
+    const bool live = row0 < a.rows;
+
+    int firstDiag = 0, diags = 0;
+    long long slab = 0;
+    if (live) {
+        const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
+        const unsigned hack = r0 / hs;
+        firstDiag = a.hackOffsets[hack];
+        diags = a.hackOffsets[hack + 1] - firstDiag;
+        slab = (long long)firstDiag * hs + (r0 - hack * hs);
+    }
+    const int waveDiags = waveMax(diags); /* wave-uniform trip count */
+
+    bool rowLive[RPL];
+    T sum[RPL];
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) {
+        rowLive[t] = row0 + t < a.rows;
+        sum[t] = zeroOf<T>();
+    }
+
+    const T* __restrict__ vals = a.dM + slab;
+    const int* __restrict__ offs = a.offsets + firstDiag;
+    const T* __restrict__ x = a.x;
+
+    for (int dBase = 0; dBase < waveDiags; dBase += UNROLL) {
+        int off[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            off[u] = dBase + u < diags ? offs[dBase + u] : 0;
+
+        Pack<T, RPL> v[UNROLL];
+        T xv[UNROLL][RPL];
+        bool use[UNROLL][RPL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long long col0 = row0 + off[u];
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                const long long col = col0 + t;
+                use[u][t] = dBase + u < diags && rowLive[t] && col >= 0 && col < a.cols;
+                any = any || use[u][t];
+                xv[u][t] = x[use[u][t] ? col : 0];
+            }
+            if (any) {
+                v[u] = loadPack<NT, T, RPL>(vals + (long long)(dBase + u) * a.hackSize);
+            } else {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    v[u].v[t] = zeroOf<T>();
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                const T next = mulAdd(v[u].v[t], xv[u][t], sum[t]);
+                sum[t] = use[u][t] ? next : sum[t];
+            }
+        }
+    }
+
+    if (!live)
+        return;
+
+    const bool hasBeta = isNotZero(a.beta);
+    if (a.wideIO && row0 + RPL <= a.rows) {
+        Pack<T, RPL> out;
+        if (hasBeta) {
+            const Pack<T, RPL> yv = loadPack<false, T, RPL>(a.y + row0);
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                out.v[t] = epilogue<true>(a.alpha, sum[t], a.beta, yv.v[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                out.v[t] = epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
+        }
+        storePack<T, RPL>(a.z + row0, out);
+    } else {
+#pragma unroll
+        for (int t = 0; t < RPL; ++t) {
+            if (rowLive[t])
+                a.z[row0 + t] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[row0 + t])
+                                        : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
+        }
+    }
+}
+
+template <typename T, int RPL, int UNROLL>
+static void launchHdia(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
+{
+    const long long strips = ((long long)a.rows + RPL - 1) / RPL;
+    const unsigned blocks = (unsigned)((strips + kHdiaThreads - 1) / kHdiaThreads);
+    if (nt)
+        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, true, UNROLL>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, false, UNROLL>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
+}
+
+template <typename T, typename ApiT>
+static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, const ApiT* dM, const int* offsets,
+                     int hackSize, const int* hackOffsets, int rows, int cols, const ApiT* x, ApiT beta)
+{
+    static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
+    if (rows <= 0 || hackSize <= 0)
+        return;
+    HdiaArgs<T> a;
+    a.z = reinterpret_cast<T*>(z);
+    a.y = reinterpret_cast<const T*>(y);
+    a.x = reinterpret_cast<const T*>(x);
+    a.dM = reinterpret_cast<const T*>(dM);
+    a.offsets = offsets;
+    a.hackOffsets = hackOffsets;
+    __builtin_memcpy(&a.alpha, &alpha, sizeof(T));
+    __builtin_memcpy(&a.beta, &beta, sizeof(T));
+    a.rows = rows;
+    a.cols = cols;
+    a.hackSize = hackSize;
+
+    constexpr int WIDE = 16 / (int)sizeof(T);
+    const char* env = getenv("SPGPU_NT_LOADS");
+    const bool nt = !(env && *env == '0');
+    const char* force = getenv("SPGPU_HDIA_NARROW");
+    const bool wideOk = WIDE > 1 && hackSize % WIDE == 0 && ((uintptr_t)dM % 16 == 0) && !(force && *force == '1');
+
+    hipStream_t stream = handle->currentStream;
+    if constexpr (WIDE > 1) {
+        if (wideOk) {
+            a.wideIO = ((uintptr_t)z % 16 == 0) && ((uintptr_t)y % 16 == 0);
+            launchHdia<T, WIDE, 4>(stream, a, nt);
+            spgpuDebugCheck(handle, "hdiaspmv");
+            return;
+        }
+    }
+    a.wideIO = 1;
+    launchHdia<T, 1, 4>(stream, a, nt);
+    spgpuDebugCheck(handle, "hdiaspmv");
+}
+
+} // namespace spgpu
+
+using namespace spgpu;
+
+extern "C" {
+
+void spgpuShdiaspmv(spgpuHandle_t handle, float* z, const float* y, float alpha, const float* dM,
+                    const int* offsets, int hackSize, const int* hackOffsets, int rows, int cols,
+                    const float* x, float beta)
+{
+    hdiaSpmv<float>(handle, z, y, alpha, dM, offsets, hackSize, hackOffsets, rows, cols, x, beta);
+}
+
+void spgpuDhdiaspmv(spgpuHandle_t handle, double* z, const double* y, double alpha, const double* dM,
+                    const int* offsets, int hackSize, const int* hackOffsets, int rows, int cols,
+                    const double* x, double beta)
+{
+    hdiaSpmv<double>(handle, z, y, alpha, dM, offsets, hackSize, hackOffsets, rows, cols, x, beta);
+}
+
+void spgpuChdiaspmv(spgpuHandle_t handle, hipFloatComplex* z, const hipFloatComplex* y, hipFloatComplex alpha,
+                    const hipFloatComplex* dM, const int* offsets, int hackSize, const int* hackOffsets,
+                    int rows, int cols, const hipFloatComplex* x, hipFloatComplex beta)
+{
+    hdiaSpmv<cfloat>(handle, z, y, alpha, dM, offsets, hackSize, hackOffsets, rows, cols, x, beta);
+}
+
+void spgpuZhdiaspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleComplex* y, hipDoubleComplex alpha,
+                    const hipDoubleComplex* dM, const int* offsets, int hackSize, const int* hackOffsets,
+                    int rows, int cols, const hipDoubleComplex* x, hipDoubleComplex beta)
+{
+    hdiaSpmv<cdouble>(handle, z, y, alpha, dM, offsets, hackSize, hackOffsets, rows, cols, x, beta);
+}
+
+} // extern "C"

@@ -1,0 +1,123 @@
+#pragma once
+/*
+ * Device-side arithmetic shared by every kernel: the four value types of the
+ * ABI (float, double, float complex, double complex), their multiply-add in
+ * the operation order the reference uses, vector-width global loads and
+ * wavefront (64-lane) shuffles.
+ *
+ * Arithmetic model (reference: kernels/hell_spmv_base.cuh:29-51):
+ *   real    fma(a,b,c) is written (a*b)+c there and contracts to one fused
+ *           multiply-add under nvcc's default -fmad; here it IS one fma.
+ *   complex fma is cuCfma / cuCfmaf; the same expression tree as
+ *           hipCfma (amd_hip_complex.h), contracted.
+ * oracle/spgpu_oracle.c uses the identical expression trees with C fma(), so
+ * the kernels and the oracle agree to the last bit whenever they also agree
+ * on the order in which a row's products are added.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spgpu {
+
+constexpr int kWave = 64;
+
+template <typename R> struct Cx { R x, y; };
+using cfloat = Cx<float>;
+using cdouble = Cx<double>;
+
+/* ---- zero / tests ------------------------------------------------------- */
+template <typename T> __device__ __host__ inline T zeroOf();
+template <> __device__ __host__ inline float zeroOf<float>() { return 0.0f; }
+template <> __device__ __host__ inline double zeroOf<double>() { return 0.0; }
+template <> __device__ __host__ inline cfloat zeroOf<cfloat>() { return cfloat{0.0f, 0.0f}; }
+template <> __device__ __host__ inline cdouble zeroOf<cdouble>() { return cdouble{0.0, 0.0}; }
+
+__device__ __host__ inline bool isNotZero(float a) { return a != 0.0f; }
+__device__ __host__ inline bool isNotZero(double a) { return a != 0.0; }
+template <typename R> __device__ __host__ inline bool isNotZero(Cx<R> a) { return a.x != R(0) || a.y != R(0); }
+
+/* ---- real --------------------------------------------------------------- */
+__device__ inline float mulAdd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ inline double mulAdd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ inline float mul(float a, float b) { return a * b; }
+__device__ inline double mul(double a, double b) { return a * b; }
+__device__ __host__ inline float add(float a, float b) { return a + b; }
+__device__ __host__ inline double add(double a, double b) { return a + b; }
+
+/* ---- complex: p*q + r with the cuCfma expression tree --------------------
+ *   re = (p.x*q.x + r.x) - p.y*q.y ;  im = (q.x*p.y + r.y) + p.x*q.y      */
+template <typename R> __device__ inline Cx<R> mulAdd(Cx<R> p, Cx<R> q, Cx<R> r)
+{
+    R re = mulAdd(p.x, q.x, r.x);
+    R im = mulAdd(q.x, p.y, r.y);
+    re = mulAdd(-p.y, q.y, re);
+    im = mulAdd(p.x, q.y, im);
+    return Cx<R>{re, im};
+}
+/* cuCmul: re = a.x*b.x - a.y*b.y ; im = a.x*b.y + a.y*b.x (second product fused in). */
+template <typename R> __device__ inline Cx<R> mul(Cx<R> a, Cx<R> b)
+{
+    return Cx<R>{mulAdd(a.x, b.x, -(a.y * b.y)), mulAdd(a.x, b.y, a.y * b.x)};
+}
+template <typename R> __device__ __host__ inline Cx<R> add(Cx<R> a, Cx<R> b) { return Cx<R>{a.x + b.x, a.y + b.y}; }
+
+/* ---- SpMV epilogue (reference: hell_spmv_base_template.cuh:219-222) ------ */
+template <bool HAS_BETA, typename T> __device__ inline T epilogue(T alpha, T rowSum, T beta, T yVal)
+{
+    if constexpr (HAS_BETA)
+        return mulAdd(beta, yVal, mul(alpha, rowSum));
+    else
+        return mul(alpha, rowSum);
+}
+
+/* ---- N consecutive elements moved by ONE global load/store -------------- */
+template <typename E, int N> struct alignas(sizeof(E) * N) Pack { E v[N]; };
+
+template <int BYTES> struct RawBits;
+template <> struct RawBits<4> { using type = uint32_t; };
+template <> struct RawBits<8> { using type = uint32_t __attribute__((ext_vector_type(2))); };
+template <> struct RawBits<16> { using type = uint32_t __attribute__((ext_vector_type(4))); };
+
+/* NT = streamed once: non-temporal hint keeps the coefficient/index streams
+ * from displacing x in the L2 / Infinity Cache. */
+template <bool NT, typename E, int N> __device__ inline Pack<E, N> loadPack(const E* p)
+{
+    using Raw = typename RawBits<sizeof(E) * N>::type;
+    Raw raw;
+    if constexpr (NT)
+        raw = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(p));
+    else
+        raw = *reinterpret_cast<const Raw*>(p);
+    Pack<E, N> out;
+    __builtin_memcpy(&out, &raw, sizeof(out));
+    return out;
+}
+
+template <typename E, int N> __device__ inline void storePack(E* p, const Pack<E, N>& value)
+{
+    using Raw = typename RawBits<sizeof(E) * N>::type;
+    Raw raw;
+    __builtin_memcpy(&raw, &value, sizeof(raw));
+    *reinterpret_cast<Raw*>(p) = raw;
+}
+
+/* ---- wavefront shuffles (lower to DPP / ds_bpermute, no LDS allocation) -- */
+__device__ inline float laneXor(float v, int mask) { return __shfl_xor(v, mask, kWave); }
+__device__ inline double laneXor(double v, int mask) { return __shfl_xor(v, mask, kWave); }
+__device__ inline int laneXor(int v, int mask) { return __shfl_xor(v, mask, kWave); }
+template <typename R> __device__ inline Cx<R> laneXor(Cx<R> v, int mask)
+{
+    return Cx<R>{laneXor(v.x, mask), laneXor(v.y, mask)};
+}
+
+__device__ inline int waveMax(int v)
+{
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+        const int other = laneXor(v, m);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+} // namespace spgpu

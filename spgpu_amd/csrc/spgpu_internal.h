@@ -1,0 +1,38 @@
+#pragma once
+/* Library-private declarations shared by the host C files and the HIP kernels. */
+#include "spgpu/core.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPGPU_HANDLE_MAGIC 0x53504750u /* 'SPGP' */
+
+/* Reduction scratch: up to SPGPU_REDUCE_MAX_BLOCKS partials of the widest
+ * type (double complex, 16 B) per reduction call. */
+#define SPGPU_REDUCE_MAX_BLOCKS 1024
+#define SPGPU_REDUCE_SCRATCH_BYTES (SPGPU_REDUCE_MAX_BLOCKS * 16)
+
+/* The public struct is the FIRST member, so a spgpuHandle_t is also a pointer
+ * to this record. */
+typedef struct SpgpuPrivateHandle {
+    SpgpuHandleStruct pub;
+    unsigned magic;
+    void* reduceScratch; /* device, SPGPU_REDUCE_SCRATCH_BYTES */
+    void* reduceHost;    /* pinned host mirror of reduceScratch */
+} SpgpuPrivateHandle;
+
+static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
+{
+    return (SpgpuPrivateHandle*)(void*)h;
+}
+
+/* With -DSPGPU_DEBUG every launch is followed by a synchronising error check
+ * that prints and exits, as the reference does under -DDEBUG
+ * (kernels/cudadebug.h:12-25).  Otherwise launch errors surface through the
+ * caller's own hipGetLastError(), again as in the reference. */
+void spgpuDebugCheck(spgpuHandle_t h, const char* what);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,124 @@
+"""Synthetic inputs of BASELINE.json / SURVEY.md section 8(d), all seeded.
+
+Small/medium cases are produced as COO on the host (numpy) so that they run
+through the same converters as a Matrix Market file would in the reference's
+harness.  Generators are deterministic functions of their arguments.
+"""
+import numpy as np
+
+_MASK64 = (1 << 64) - 1
+
+
+def splitmix64(seed, idx):
+    """Vectorised splitmix64 of (seed, idx) -> uint64 (column / value hashes)."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(idx, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+             + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed, n, dtype=np.float64):
+    """U[0,1) vector from splitmix64(seed, i)."""
+    u = (splitmix64(seed, np.arange(n, dtype=np.uint64)) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    return u.astype(dtype)
+
+
+def values_for(letter, seed, n):
+    """Random coefficients/vectors of the API flavour S/D/C/Z in [-1, 1) (+ i[-1,1))."""
+    real = {"S": np.float32, "D": np.float64, "C": np.float32, "Z": np.float64}[letter]
+    re = (2.0 * uniform01(seed, n) - 1.0).astype(real)
+    if letter in "SD":
+        return re
+    im = (2.0 * uniform01(seed + 7919, n) - 1.0).astype(real)
+    return (re + 1j * im).astype(np.complex64 if letter == "C" else np.complex128)
+
+
+def hashed_vector(n, multiplier=2654435761, dtype=np.float64):
+    """x_i = ((i * multiplier) mod 2^32) / 2^32  (SURVEY 8(d), config C1)."""
+    i = np.arange(n, dtype=np.uint64)
+    return (((i * np.uint64(multiplier)) & np.uint64(0xFFFFFFFF)).astype(np.float64) / 4294967296.0).astype(dtype)
+
+
+def laplacian_2d_5pt(n, dtype=np.float64, base=0):
+    """5-point Laplacian on an n x n grid, natural order; per row ascending columns
+    (-n, -1, 0, +1, +n); diagonal 4, off-diagonal -1 (SURVEY 8(a) generator)."""
+    N = n * n
+    i = np.arange(N, dtype=np.int64)
+    gx, gy = i % n, i // n
+    parts = [
+        (gy > 0, i - n, -1.0), (gx > 0, i - 1, -1.0), (np.ones(N, bool), i, 4.0),
+        (gx < n - 1, i + 1, -1.0), (gy < n - 1, i + n, -1.0),
+    ]
+    return _assemble_row_major(N, i, parts, dtype, base)
+
+
+def laplacian_3d_7pt(m, dtype=np.float64, base=0):
+    """7-point Laplacian on an m^3 grid, natural order; per row ascending columns
+    (-m^2, -m, -1, 0, +1, +m, +m^2); diagonal 6, off-diagonal -1."""
+    N = m * m * m
+    i = np.arange(N, dtype=np.int64)
+    gx, gy, gz = i % m, (i // m) % m, i // (m * m)
+    parts = [
+        (gz > 0, i - m * m, -1.0), (gy > 0, i - m, -1.0), (gx > 0, i - 1, -1.0),
+        (np.ones(N, bool), i, 6.0),
+        (gx < m - 1, i + 1, -1.0), (gy < m - 1, i + m, -1.0), (gz < m - 1, i + m * m, -1.0),
+    ]
+    return _assemble_row_major(N, i, parts, dtype, base)
+
+
+def _assemble_row_major(N, i, parts, dtype, base):
+    """Interleave per-stencil-point (mask, col, value) so that entries are row-major."""
+    k = len(parts)
+    mask = np.stack([p[0] for p in parts], axis=1)           # N x k
+    cols = np.stack([p[1] for p in parts], axis=1)
+    vals = np.broadcast_to(np.array([p[2] for p in parts], dtype=np.float64), (N, k))
+    rows = np.broadcast_to(i[:, None], (N, k))
+    sel = mask.reshape(-1)
+    return (N, N, (rows.reshape(-1)[sel] + base).astype(np.int32), (cols.reshape(-1)[sel] + base).astype(np.int32),
+            vals.reshape(-1)[sel].astype(dtype))
+
+
+def ctest_matrix(dtype=np.float32):
+    """The matrix of the reference's ctest.c:25-39: 100x100, 200 entries, rows[i]=cols[i]=i%100, value 1."""
+    e = np.arange(200, dtype=np.int32)
+    return 100, 100, (e % 100).astype(np.int32), (e % 100).astype(np.int32), np.ones(200, dtype=dtype)
+
+
+def power_law_lengths(n_rows, mean=32.0, max_len=2048, seed=5, exponent=2.0):
+    """Row lengths min(max_len, floor(c * u^(-1/exponent))), c tuned so that the mean is ~`mean`
+    (SURVEY 8(d), config C3)."""
+    u = np.maximum(uniform01(seed, n_rows), 1e-12)
+    shape = u ** (-1.0 / exponent)
+    lo, hi = 0.01, float(max_len)
+    for _ in range(60):
+        c = 0.5 * (lo + hi)
+        m = np.minimum(max_len, np.floor(c * shape)).mean()
+        lo, hi = (c, hi) if m < mean else (lo, c)
+    return np.maximum(1, np.minimum(max_len, np.floor(0.5 * (lo + hi) * shape))).astype(np.int32)
+
+
+def random_rows_coo(n_rows, n_cols, lengths, seed=1, letter="D", base=0, shuffle=False):
+    """COO with `lengths[r]` entries in row r, columns splitmix64(seed, slot) mod n_cols,
+    row-major order (optionally a seeded shuffle of the entry order)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    nnz = int(lengths.sum())
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), lengths)
+    cols = (splitmix64(seed, np.arange(nnz, dtype=np.uint64)) % np.uint64(max(n_cols, 1))).astype(np.int64)
+    vals = values_for(letter, seed + 1, nnz)
+    if shuffle:
+        perm = np.argsort(splitmix64(seed + 2, np.arange(nnz, dtype=np.uint64)), kind="stable")
+        rows, cols, vals = rows[perm], cols[perm], vals[perm]
+    return n_rows, n_cols, (rows + base).astype(np.int32), (cols + base).astype(np.int32), vals
+
+
+def banded_coo(n, half_width=16, letter="D", seed=2, base=0):
+    """n x n band: row i has columns i-half_width .. i+half_width-1 clipped to [0, n)."""
+    i = np.arange(n, dtype=np.int64)[:, None]
+    c = i + np.arange(-half_width, half_width, dtype=np.int64)[None, :]
+    ok = (c >= 0) & (c < n)
+    rows = np.broadcast_to(i, c.shape)[ok]
+    cols = c[ok]
+    vals = values_for(letter, seed, rows.size)
+    return n, n, (rows + base).astype(np.int32), (cols + base).astype(np.int32), vals

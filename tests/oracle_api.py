@@ -1,0 +1,229 @@
+"""TEST INFRASTRUCTURE: ctypes access to oracle/liboracle.so (the CPU restatement)
+and, through its lazy loader, to oracle/_ref/libspgpu_ref.so (the reference's own
+host converters compiled from /root/reference; see oracle/Makefile)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_PATH = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libspgpu_ref.so")
+
+orc = C.CDLL(ORACLE_PATH)
+orc.orc_sizeOf.restype = C.c_size_t
+orc.orc_fnv1a64.restype = C.c_uint64
+orc.orc_fnv1a64.argtypes = [C.c_void_p, C.c_size_t]
+orc.orc_ref_open.argtypes = [C.c_char_p, C.POINTER(C.c_char_p)]
+orc.orc_ref_symbol.restype = C.c_void_p
+orc.orc_ref_symbol.argtypes = [C.c_char_p]
+
+NP_DTYPE = {"S": np.float32, "D": np.float64, "C": np.complex64, "Z": np.complex128}
+TYPE_CODE = {"S": 1, "D": 2, "C": 3, "Z": 4}
+LETTER_OF = {np.dtype(v): k for k, v in NP_DTYPE.items()}
+ptr, i32 = C.c_void_p, C.c_int
+
+
+class FloatComplex(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float)]
+
+
+class DoubleComplex(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double)]
+
+
+SCALAR = {"S": C.c_float, "D": C.c_double, "C": FloatComplex, "Z": DoubleComplex}
+
+
+def scalar(letter, value):
+    if letter in "SD":
+        return SCALAR[letter](float(value))
+    v = complex(value)
+    return SCALAR[letter](v.real, v.imag)
+
+
+def fnv(a):
+    a = np.ascontiguousarray(a)
+    return "%016x" % orc.orc_fnv1a64(C.c_void_p(a.ctypes.data), a.nbytes)
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+_CONV_SIGS = {
+    "computeEllRowLenghts": (None, [ptr, C.POINTER(i32), i32, i32, ptr, i32]),
+    "computeEllAllocPitch": (i32, [i32]),
+    "cooToEll": (None, [ptr, ptr, i32, i32, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32]),
+    "computeHellAllocSize": (None, [C.POINTER(i32), i32, i32, ptr]),
+    "ellToHell": (None, [ptr, ptr, ptr, i32, ptr, ptr, i32, i32, ptr, i32, i32]),
+    "getHdiaHacksCount": (i32, [i32, i32]),
+    "computeHdiaHackOffsetsFromCoo": (None, [C.POINTER(i32), ptr, i32, i32, i32, i32, ptr, ptr, i32]),
+    "cooToHdia": (None, [ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32]),
+}
+
+
+class ConverterSet:
+    """The eight converter entry points of one implementation, as Python callables."""
+
+    def __init__(self, resolve, label):
+        self.label = label
+        for name, (res, args) in _CONV_SIGS.items():
+            setattr(self, name, resolve(name, res, args))
+
+    # Same driving sequence as spgpu_amd.formats (hellPerf.cpp:136-152,254-264; diaPerf.cpp:254-293).
+    def coo_to_ell(self, n_rows, rows, cols, vals, coo_base=0, ell_base=0):
+        rows, cols = np.ascontiguousarray(rows, np.int32), np.ascontiguousarray(cols, np.int32)
+        vals = np.ascontiguousarray(vals)
+        letter = LETTER_OF[vals.dtype]
+        row_len = np.zeros(max(n_rows, 1), np.int32)
+        max_row = i32(0)
+        self.computeEllRowLenghts(_p(row_len), C.byref(max_row), n_rows, rows.size, _p(rows), coo_base)
+        pitch = self.computeEllAllocPitch(n_rows)
+        values = np.zeros(max(max_row.value * pitch, 1), vals.dtype)
+        indices = np.zeros(max(max_row.value * pitch, 1), np.int32)
+        self.cooToEll(_p(values), _p(indices), pitch, pitch, max_row.value, ell_base, n_rows, rows.size,
+                      _p(rows), _p(cols), _p(vals), coo_base, TYPE_CODE[letter])
+        return dict(letter=letter, rows=n_rows, values=values[:max_row.value * pitch],
+                    indices=indices[:max_row.value * pitch], pitch=pitch, max_row=max_row.value,
+                    row_lengths=row_len[:n_rows], base=ell_base)
+
+    def ell_to_hell(self, ell, hack_size=32):
+        n_rows = ell["rows"]
+        row_len = np.ascontiguousarray(ell["row_lengths"], np.int32)
+        height = i32(0)
+        self.computeHellAllocSize(C.byref(height), hack_size, n_rows, _p(row_len))
+        slots = hack_size * height.value
+        hacks = (n_rows + hack_size - 1) // hack_size
+        values = np.zeros(max(slots, 1), ell["values"].dtype)
+        indices = np.zeros(max(slots, 1), np.int32)
+        hack_offsets = np.zeros(max(hacks, 1), np.int32)
+        ev = ell["values"] if ell["values"].size else np.zeros(1, ell["values"].dtype)
+        ei = ell["indices"] if ell["indices"].size else np.zeros(1, np.int32)
+        self.ellToHell(_p(values), _p(indices), _p(hack_offsets), hack_size, _p(ev), _p(ei), ell["pitch"],
+                       ell["pitch"], _p(row_len), n_rows, TYPE_CODE[ell["letter"]])
+        return dict(letter=ell["letter"], rows=n_rows, values=values[:slots], indices=indices[:slots],
+                    hack_offsets=hack_offsets[:hacks], hack_size=hack_size, height=height.value,
+                    row_lengths=row_len, base=ell["base"])
+
+    def coo_to_hdia(self, n_rows, n_cols, rows, cols, vals, hack_size=32, coo_base=0):
+        rows, cols = np.ascontiguousarray(rows, np.int32), np.ascontiguousarray(cols, np.int32)
+        vals = np.ascontiguousarray(vals)
+        letter = LETTER_OF[vals.dtype]
+        hacks = self.getHdiaHacksCount(hack_size, n_rows)
+        hack_offsets = np.zeros(hacks + 1, np.int32)
+        height = i32(0)
+        self.computeHdiaHackOffsetsFromCoo(C.byref(height), _p(hack_offsets), hack_size, n_rows, n_cols,
+                                           rows.size, _p(rows), _p(cols), coo_base)
+        values = np.zeros(max(hack_size * height.value, 1), vals.dtype)
+        offsets = np.zeros(max(height.value, 1), np.int32)
+        self.cooToHdia(_p(values), _p(offsets), _p(hack_offsets), hack_size, n_rows, n_cols, rows.size,
+                       _p(rows), _p(cols), _p(vals), coo_base, TYPE_CODE[letter])
+        return dict(letter=letter, rows=n_rows, cols=n_cols, values=values[:hack_size * height.value],
+                    offsets=offsets[:height.value], hack_offsets=hack_offsets, hack_size=hack_size,
+                    height=height.value)
+
+
+def _resolve_oracle(name, res, args):
+    fn = getattr(orc, "orc_" + name)
+    fn.restype, fn.argtypes = res, args
+    return fn
+
+
+oracle_converters = ConverterSet(_resolve_oracle, "oracle")
+
+
+def reference_available():
+    return os.path.exists(REF_PATH)
+
+
+_ref_set = None
+
+
+def reference_converters():
+    """The reference's own converters (oracle/_ref), or None when that build is absent."""
+    global _ref_set
+    if _ref_set is None and reference_available():
+        err = C.c_char_p()
+        if orc.orc_ref_open(REF_PATH.encode(), C.byref(err)) != 0:
+            raise RuntimeError(f"cannot open {REF_PATH}: {err.value}")
+
+        def resolve(name, res, args):
+            addr = orc.orc_ref_symbol(name.encode())
+            if not addr:
+                raise RuntimeError(f"{name} missing from {REF_PATH}")
+            return C.CFUNCTYPE(res, *args)(addr)
+
+        _ref_set = ConverterSet(resolve, "reference")
+    return _ref_set
+
+
+# ---- SpMV / level-1 oracles ---------------------------------------------------------
+_LOW = {"S": "s", "D": "d", "C": "c", "Z": "z"}
+for _L, _T in SCALAR.items():
+    _l = _LOW[_L]
+    getattr(orc, f"orc_{_l}hellspmv").argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, ptr, ptr, i32, ptr, _T, i32, i32]
+    getattr(orc, f"orc_{_l}ellspmv").argtypes = [ptr, ptr, _T, ptr, ptr, i32, i32, ptr, ptr, i32, i32, ptr, _T, i32, i32]
+    getattr(orc, f"orc_{_l}hdiaspmv").argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, _T]
+    getattr(orc, f"orc_{_l}axpby").argtypes = [ptr, i32, _T, ptr, _T, ptr]
+    getattr(orc, f"orc_{_l}dot").argtypes = [ptr, i32, ptr, ptr]
+    getattr(orc, f"orc_{_l}nrm2").argtypes = [ptr, i32, ptr]
+    for _n in ("hellspmv", "ellspmv", "hdiaspmv", "axpby", "dot", "nrm2"):
+        getattr(orc, f"orc_{_l}{_n}").restype = None
+
+
+def hell_spmv(hell, x, y, alpha, beta, r_idx=None, phases=1):
+    L = hell["letter"]
+    z = np.zeros(hell["rows"], NP_DTYPE[L]) if y is None else np.array(y, NP_DTYPE[L], copy=True)
+    yy = None if y is None else np.ascontiguousarray(y, NP_DTYPE[L])
+    ri = None if r_idx is None else np.ascontiguousarray(r_idx, np.int32)
+    getattr(orc, f"orc_{_LOW[L]}hellspmv")(_p(z), _p(yy), scalar(L, alpha), _p(hell["values"]), _p(hell["indices"]),
+                                           hell["hack_size"], _p(hell["hack_offsets"]), _p(hell["row_lengths"]),
+                                           _p(ri), hell["rows"], _p(np.ascontiguousarray(x, NP_DTYPE[L])),
+                                           scalar(L, beta), hell["base"], phases)
+    return z
+
+
+def ell_spmv(ell, x, y, alpha, beta, r_idx=None, phases=1, with_row_sizes=True):
+    L = ell["letter"]
+    z = np.zeros(ell["rows"], NP_DTYPE[L]) if y is None else np.array(y, NP_DTYPE[L], copy=True)
+    yy = None if y is None else np.ascontiguousarray(y, NP_DTYPE[L])
+    ri = None if r_idx is None else np.ascontiguousarray(r_idx, np.int32)
+    rs = ell["row_lengths"] if with_row_sizes else None
+    getattr(orc, f"orc_{_LOW[L]}ellspmv")(_p(z), _p(yy), scalar(L, alpha), _p(ell["values"]), _p(ell["indices"]),
+                                          ell["pitch"], ell["pitch"], _p(rs), _p(ri), ell["max_row"], ell["rows"],
+                                          _p(np.ascontiguousarray(x, NP_DTYPE[L])), scalar(L, beta), ell["base"], phases)
+    return z
+
+
+def hdia_spmv(hdia, x, y, alpha, beta):
+    L = hdia["letter"]
+    z = np.zeros(hdia["rows"], NP_DTYPE[L]) if y is None else np.array(y, NP_DTYPE[L], copy=True)
+    yy = None if y is None else np.ascontiguousarray(y, NP_DTYPE[L])
+    getattr(orc, f"orc_{_LOW[L]}hdiaspmv")(_p(z), _p(yy), scalar(L, alpha), _p(hdia["values"]), _p(hdia["offsets"]),
+                                           hdia["hack_size"], _p(hdia["hack_offsets"]), hdia["rows"], hdia["cols"],
+                                           _p(np.ascontiguousarray(x, NP_DTYPE[L])), scalar(L, beta))
+    return z
+
+
+def axpby(letter, n, beta, y, alpha, x):
+    z = np.zeros(n, NP_DTYPE[letter])
+    getattr(orc, f"orc_{_LOW[letter]}axpby")(_p(z), n, scalar(letter, beta),
+                                             _p(np.ascontiguousarray(y, NP_DTYPE[letter])) if y is not None else None,
+                                             scalar(letter, alpha), _p(np.ascontiguousarray(x, NP_DTYPE[letter])))
+    return z
+
+
+def dot(letter, a, b):
+    out = np.zeros(1, NP_DTYPE[letter])
+    a, b = np.ascontiguousarray(a, NP_DTYPE[letter]), np.ascontiguousarray(b, NP_DTYPE[letter])
+    getattr(orc, f"orc_{_LOW[letter]}dot")(_p(out), a.size, _p(a), _p(b))
+    return out[0]
+
+
+def nrm2(letter, a):
+    real = {"S": np.float32, "D": np.float64, "C": np.float32, "Z": np.float64}[letter]
+    out = np.zeros(1, real)
+    a = np.ascontiguousarray(a, NP_DTYPE[letter])
+    getattr(orc, f"orc_{_LOW[letter]}nrm2")(_p(out), a.size, _p(a))
+    return out[0]
