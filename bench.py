@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of BASELINE.json measured on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W          # headline: HELL fp64 SpMV (configs[1])
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # row-sharded SpMM
+
+A "step" is one pass of the hot path over the synthetic input, inputs resident in HBM:
+  N == 1 : one spgpuDhellspmv on BASELINE configs[1] (10 M rows, 32 nnz/row uniform, hackSize 32, fp64)
+  N  > 1 : one row-sharded HELL fp64 SpMM step (A x 16 rhs, 5 M rows per GPU; all-gather of X over RCCL,
+           then spgpuDhellspmm on the local row block) -- the only part of the path that shards
+           (north_star: "single-vector SpMV stays single-GPU").
+Rank 0 prints ONE JSON line.  metric = GFLOP/s (2*nnz per SpMV, 64-bit; the reference's harness uses
+2*nnz-1, hellPerf.cpp:316); roofline = algorithmic HBM bytes / measured kernel time
+against 8 TB/s; cpu_baseline = the oracle (a port: the reference has no CPU SpMV) timed on this box's
+host cores on a bounded sample.  Only that leg and the parity spot-check touch oracle/.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--rows", type=int, default=10_000_000, help="rows of the SpMV workload (configs[1]: 10 M)")
+    p.add_argument("--nnz-per-row", type=int, default=32)
+    p.add_argument("--pattern", default="banded", choices=["banded", "random", "window"],
+                   help="column pattern of the headline workload (SURVEY 8(d) C2 defines banded and random)")
+    p.add_argument("--no-extras", action="store_true", help="skip the untimed extra variants and the CPU baseline")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg")
+    p.add_argument("--spmm-rows-per-gpu", type=int, default=5_000_000)
+    p.add_argument("--rhs", type=int, default=16)
+    return p.parse_args()
+
+
+def hell_algorithmic_bytes(nnz, rows, cols, hacks, elem=8, beta_nonzero=False, rhs=1):
+    """padding and cache-line over-fetch do not count; x counted once."""
+    matrix = nnz * (elem + 4) + rows * 4 + hacks * 4
+    vectors = cols * elem + rows * elem * (2 if beta_nonzero else 1)
+    return matrix + rhs * vectors
+
+
+def time_launches(stream, fn, steps):
+    """HIP events on the stream the kernels are launched on; returns seconds for `steps` launches."""
+    import torch
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        start.record(stream)
+        for _ in range(steps):
+            fn()
+        stop.record(stream)
+    stop.synchronize()
+    return start.elapsed_time(stop) * 1e-3
+
+
+def spot_check_hell(h, x, y, z, alpha, beta, phases=4, rows_per_probe=2048):
+    """Parity at full size: three hack-aligned row windows of the device result against the oracle."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as O
+    from spgpu_amd import synth
+    xs = x.cpu().numpy()
+    n = h["rows"]
+    for first in (0, (n // 2) // h["hack_size"] * h["hack_size"], n - rows_per_probe):
+        sub = synth.hell_rows_to_host(h, first, rows_per_probe)
+        ys = y[first:first + rows_per_probe].cpu().numpy() if beta != 0 else None
+        want = O.hell_spmv(sub, xs, ys, alpha, beta, phases=phases)
+        got = z[first:first + rows_per_probe].cpu().numpy()
+        if got.tobytes() != want.tobytes():
+            return f"MISMATCH in rows [{first},{first + rows_per_probe})"
+    return "bit-exact vs oracle on 3 x %d rows" % rows_per_probe
+
+
+def cpu_baseline(h, x, seconds):
+    """The oracle's HELL SpMV (OpenMP over rows) on the first rows of the same matrix."""
+    import numpy as np
+    import oracle_api as O
+    from spgpu_amd import synth
+    sample_rows = min(h["rows"], 2_000_000) // h["hack_size"] * h["hack_size"]
+    sub = synth.hell_rows_to_host(h, 0, sample_rows)
+    xs = x.cpu().numpy()
+    nnz = int(sub["row_lengths"].sum(dtype=np.int64))
+    O.hell_spmv(sub, xs, None, 1.0, 0.0)  # warm the pages
+    t0, passes = time.perf_counter(), 0
+    while True:
+        O.hell_spmv(sub, xs, None, 1.0, 0.0)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or passes >= 200:
+            break
+    cores = int(O.orc.orc_threads())
+    return dict(value=round(2.0 * nnz * passes / dt * 1e-9, 3), unit="GFLOP/s", cores=cores, kind="port",
+                sample=f"oracle orc_dhellspmv (OpenMP, {cores} threads) on the first {sample_rows} rows "
+                       f"({nnz} nnz) of the same matrix, {passes} passes in {dt:.1f} s")
+
+
+def run_spmv(args, rank, world):
+    import torch
+    import torch.distributed as dist
+    from spgpu_amd import capi, synth
+
+    dev = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+    torch.cuda.set_device(dev)
+    handle = capi.create_handle(torch.cuda.current_device())
+    stream = torch.cuda.Stream()
+    capi.spgpuSetStream(handle, C.c_void_p(stream.cuda_stream))
+
+    def build(pattern):
+        h = synth.hell_uniform_on_device(args.rows, args.nnz_per_row, pattern, "D", 32, seed=1, device=dev)
+        return h
+
+    def launcher(h, x, y, z, alpha, beta):
+        p = lambda t: C.c_void_p(t.data_ptr())
+        a = (handle, p(z), p(y), C.c_double(alpha), p(h["cM"]), p(h["rP"]), h["hack_size"], p(h["hack_offsets"]),
+             p(h["rS"]), None, args.nnz_per_row, h["rows"], p(x), C.c_double(beta), 0)
+        return lambda: capi.hellspmv["D"](*a)
+
+    h = build(args.pattern)
+    x = synth.device_vector(h["cols"], "D", 3, dev)
+    y = synth.device_vector(h["rows"], "D", 4, dev)
+    z = torch.empty_like(y)
+    hacks = h["rows"] // h["hack_size"]
+    step = launcher(h, x, y, z, 1.0, 0.0)  # alpha = 1, beta = 0 as the reference's harness (hellPerf.cpp:27-28)
+
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+    stream.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_s = time_launches(stream, step, args.steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    flops = 2.0 * h["nnz"]
+    alg = hell_algorithmic_bytes(h["nnz"], h["rows"], h["cols"], hacks)
+    per_launch = kernel_s / args.steps
+    out = dict(
+        metric="HELL fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), 1 GPU",
+        value=round(flops * args.steps * world / wall * 1e-9, 2), unit="GFLOP/s", n_gpus=world,
+        steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 5),
+        higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+        config=dict(workload=f"HELL fp64 SpMV (spgpuDhellspmv), {h['rows']} rows x {args.nnz_per_row} nnz/row uniform, "
+                             f"hackSize 32, columns {args.pattern}, alpha=1 beta=0 (BASELINE configs[1])",
+                    rows=h["rows"], nnz=h["nnz"], hack_size=32, pattern=args.pattern,
+                    parallelism="single GPU" if world == 1 else f"{world} independent replicas"),
+        roofline=dict(bound="hbm", achieved=round(alg / per_launch * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                      frac=round(alg / per_launch * 1e-9 / HBM_PEAK_GBS, 4), traffic=None,
+                      kernel="slabSpmvKernel<double,2,4,HELL>", algorithmic_bytes_per_launch=alg,
+                      kernel_ms=round(per_launch * 1e3, 5)),
+    )
+
+    if rank == 0:
+        step()
+        torch.cuda.synchronize()
+        out["parity"] = spot_check_hell(h, x, y, z, 1.0, 0.0)
+        if not args.no_extras:
+            extras = {}
+            # beta != 0 on the headline matrix
+            s2 = launcher(h, x, y, z, 1.0, 0.5)
+            time_launches(stream, s2, 5)
+            t = time_launches(stream, s2, 50) / 50
+            a2 = hell_algorithmic_bytes(h["nnz"], h["rows"], h["cols"], hacks, beta_nonzero=True)
+            extras[f"{args.pattern}_beta0.5"] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(a2 / t * 1e-9, 1),
+                                                      frac=round(a2 / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4))
+            out["cpu_baseline"] = cpu_baseline(h, x, args.cpu_seconds)
+            for pattern in ("banded", "window", "random"):
+                if pattern == args.pattern:
+                    continue
+                del h, step, s2
+                torch.cuda.empty_cache()
+                h = build(pattern)
+                step = s2 = launcher(h, x, y, z, 1.0, 0.0)
+                time_launches(stream, step, 5)
+                t = time_launches(stream, step, 50) / 50
+                extras[pattern] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
+                                       frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4),
+                                       parity=spot_check_hell(h, x, y, z, 1.0, 0.0))
+            out["variants"] = extras
+        elif "cpu_baseline" not in out:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    capi.spgpuDestroy(handle)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl")
+    try:
+        run_spmv(args, rank, world)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

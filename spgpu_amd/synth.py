@@ -122,3 +122,80 @@ def banded_coo(n, half_width=16, letter="D", seed=2, base=0):
     cols = c[ok]
     vals = values_for(letter, seed, rows.size)
     return n, n, (rows + base).astype(np.int32), (cols + base).astype(np.int32), vals
+
+
+# ---- device-side generators for the BASELINE-size workloads (torch is plumbing) --------
+
+def hell_uniform_on_device(n_rows, nnz_per_row, pattern="random", letter="D", hack_size=32, seed=1,
+                           device="cuda:0", n_cols=None, band_offset=None):
+    """A HELL matrix with exactly `nnz_per_row` entries in every row, built directly in HBM
+    (BASELINE config 2: 10 M rows x 32).  With a uniform row length L the HELL arrays of
+    hell.c:46-104 are a dense [hacks][L][hack_size] block: slot(r, k) = (r // hs)*hs*L + r % hs + k*hs.
+
+    pattern "banded": row i has columns i-L/2 .. i+L/2-1, wrapped into [0, n_cols)   
+    pattern "random": L columns uniform over [0, n_cols), ascending within the row     
+    pattern "window": like random but inside a window of 65 536 columns around the row (locality in between)
+
+    Returns dict(letter, rows, cols, hack_size, nnz, cM, rP, hack_offsets, rS) of torch tensors.
+    """
+    import torch
+    assert n_rows % hack_size == 0, "uniform generator wants whole hacks"
+    n_cols = n_cols or n_rows
+    hacks, L, hs = n_rows // hack_size, nnz_per_row, hack_size
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    tdt = {"S": torch.float32, "D": torch.float64, "C": torch.complex64, "Z": torch.complex128}[letter]
+    rdt = {"S": torch.float32, "D": torch.float64, "C": torch.float32, "Z": torch.float64}[letter]
+
+    row = (torch.arange(hacks, device=device, dtype=torch.int64)[:, None, None] * hs
+           + torch.arange(hs, device=device, dtype=torch.int64)[None, None, :])          # [hacks,1,hs]
+    if pattern == "banded":
+        k = torch.arange(L, device=device, dtype=torch.int64)[None, :, None]
+        cols = (row + k - (L // 2 if band_offset is None else band_offset)) % n_cols
+    elif pattern == "random":
+        cols = torch.randint(0, n_cols, (hacks, L, hs), device=device, generator=gen, dtype=torch.int64)
+        cols = torch.sort(cols, dim=1).values
+    elif pattern == "window":
+        w = min(65536, n_cols)
+        cols = (row + torch.randint(-(w // 2), w // 2, (hacks, L, hs), device=device, generator=gen,
+                                    dtype=torch.int64)) % n_cols
+        cols = torch.sort(cols, dim=1).values
+    else:
+        raise ValueError(pattern)
+    rP = cols.to(torch.int32).reshape(-1).contiguous()
+    del cols, row
+    if letter in "SD":
+        cM = torch.rand(hacks * L * hs, device=device, generator=gen, dtype=rdt)
+    else:
+        cM = torch.complex(torch.rand(hacks * L * hs, device=device, generator=gen, dtype=rdt),
+                           torch.rand(hacks * L * hs, device=device, generator=gen, dtype=rdt)).to(tdt)
+    hack_offsets = (torch.arange(hacks, device=device, dtype=torch.int64) * (hs * L)).to(torch.int32)
+    rS = torch.full((n_rows,), L, device=device, dtype=torch.int32)
+    return dict(letter=letter, rows=n_rows, cols=n_cols, hack_size=hs, nnz=n_rows * L, cM=cM, rP=rP,
+                hack_offsets=hack_offsets, rS=rS, base=0, row_len=L)
+
+
+def device_vector(n, letter="D", seed=3, device="cuda:0"):
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    rdt = {"S": torch.float32, "D": torch.float64, "C": torch.float32, "Z": torch.float64}[letter]
+    if letter in "SD":
+        return torch.rand(n, device=device, generator=gen, dtype=rdt)
+    return torch.complex(torch.rand(n, device=device, generator=gen, dtype=rdt),
+                         torch.rand(n, device=device, generator=gen, dtype=rdt))
+
+
+def hell_rows_to_host(h, first_row, n_rows):
+    """Rows [first_row, first_row+n_rows) of a device HELL matrix from hell_uniform_on_device
+    (first_row and n_rows multiples of hack_size) as a host HELL dict with rebased hackOffsets:
+    the sub-range of hacks is a contiguous piece of cM / rP (cf. the reference's own chunk loop,
+    hell_spmv_base.cuh:139-144)."""
+    import numpy as np
+    hs, L = h["hack_size"], h["row_len"]
+    assert first_row % hs == 0 and n_rows % hs == 0
+    s0, s1 = (first_row // hs) * hs * L, ((first_row + n_rows) // hs) * hs * L
+    ho = h["hack_offsets"][first_row // hs:(first_row + n_rows) // hs].cpu().numpy().astype(np.int64) - s0
+    return dict(letter=h["letter"], rows=n_rows, values=h["cM"][s0:s1].cpu().numpy(),
+                indices=h["rP"][s0:s1].cpu().numpy(), hack_offsets=ho.astype(np.int32), hack_size=hs,
+                row_lengths=h["rS"][first_row:first_row + n_rows].cpu().numpy(), base=h["base"])

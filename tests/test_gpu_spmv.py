@@ -1,0 +1,236 @@
+"""GPU: parity of the HIP kernels, called through the C ABI, against the oracle and the
+golden fixtures.  Tolerance (north_star): 1e-6 (fp64) / 1e-4 (fp32) of the row magnitude;
+in addition the kernels are compared BIT FOR BIT with the oracle run in the kernel's own
+summation order (S: 8 phases, D/C: 4, Z: 2 for the wide slab kernel; 2 / 1 for the
+narrow variants), which is stricter than the contract and catches indexing slips that a
+tolerance would hide."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"S": 1e-4, "C": 1e-4, "D": 1e-6, "Z": 1e-6}
+WIDE_PHASES = {"S": 8, "D": 4, "C": 4, "Z": 2}   # default dispatch of ellpack_spmv.hip
+VARIANT_PHASES = {1: WIDE_PHASES, 2: dict.fromkeys("SDCZ", 1), 3: dict.fromkeys("SDCZ", 2), 4: dict.fromkeys("SDCZ", 1)}
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
+
+
+def _load(name):
+    with np.load(os.path.join(GOLD, name + ".npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
+def _mats(g):
+    letter = O.LETTER_OF[g["coo_vals"].dtype]
+    base, hs = int(g["base"]), int(g["hack_size"])
+    ell = dict(letter=letter, rows=int(g["n_rows"]), values=g["ell_values"], indices=g["ell_indices"],
+               pitch=int(g["ell_pitch"]), max_row=int(g["ell_max_row"]), row_lengths=g["row_lengths"], base=base)
+    hell = dict(letter=letter, rows=int(g["n_rows"]), values=g["hell_values"], indices=g["hell_indices"],
+                hack_offsets=g["hell_hack_offsets"], hack_size=hs, row_lengths=g["row_lengths"], base=base,
+                height=int(g["hell_height"]))
+    hdia = dict(letter=letter, rows=int(g["n_rows"]), cols=int(g["n_cols"]), values=g["hdia_values"],
+                offsets=g["hdia_offsets"], hack_offsets=g["hdia_hack_offsets"], hack_size=hs,
+                height=int(g["hdia_height"]))
+    return letter, ell, hell, hdia
+
+
+def _within(z, g, letter):
+    err = np.abs(z.astype(np.complex128 if letter in "CZ" else np.float64) - g["z_expected"])
+    bound = TOL[letter] * g["z_scale"] + np.finfo(np.float64).tiny
+    return float(np.max(err / bound)) if err.size else 0.0
+
+
+def _run(handle, mat, x, y, alpha, beta, in_place=False):
+    """One C-ABI SpMV call; returns z as numpy."""
+    import torch
+    from spgpu_amd import formats
+    dx = formats.to_device(x)
+    dy = formats.to_device(y) if y is not None else None
+    if in_place and dy is not None:
+        dz = dy
+    else:
+        dz = torch.full((mat.rows,), float("nan"), dtype=dx.dtype, device=dx.device)
+    mat.spmv(handle, dz, dy, alpha, dx, beta)
+    torch.cuda.synchronize()
+    return dz.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if n not in ("empty_d", "onerow_z")])
+def test_fixture_parity_all_formats(gpu, name):
+    from spgpu_amd import formats
+    g = _load(name)
+    letter, ell, hell, hdia = _mats(g)
+    alpha, beta = g["alpha"][()], g["beta"][()]
+    y = g["y"] if beta != 0 else None
+    ph = WIDE_PHASES[letter]
+
+    z = _run(gpu, formats.DeviceHell(hell), g["x"], y, alpha, beta)
+    assert _within(z, g, letter) <= 1.0
+    assert z.tobytes() == O.hell_spmv(hell, g["x"], y, alpha, beta, phases=ph).tobytes()
+
+    z = _run(gpu, formats.DeviceEll(ell), g["x"], y, alpha, beta)
+    assert _within(z, g, letter) <= 1.0
+    assert z.tobytes() == O.ell_spmv(ell, g["x"], y, alpha, beta, phases=ph).tobytes()
+
+    # rS == NULL: iterate maxNnzPerRow over the zero padding (index 0 - baseIndex may be -1: skipped)
+    z = _run(gpu, formats.DeviceEll(ell, with_row_sizes=False), g["x"], y, alpha, beta)
+    assert _within(z, g, letter) <= 1.0
+
+    key = g["coo_rows"].astype(np.int64) * (int(g["n_cols"]) + 2) + g["coo_cols"]
+    if np.unique(key).size == key.size:  # HDIA merges duplicates
+        z = _run(gpu, formats.DeviceHdia(hdia), g["x"], y, alpha, beta)
+        assert _within(z, g, letter) <= 1.0
+        assert z.tobytes() == O.hdia_spmv(hdia, g["x"], y, alpha, beta).tobytes()
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("name", ["powerlaw_s_b1_h64", "powerlaw_d_b0_h32", "powerlaw_c_b0_h32", "powerlaw_z_b1_h64"])
+def test_every_kernel_variant_bit_exact(gpu, name, variant, monkeypatch):
+    from spgpu_amd import formats
+    monkeypatch.setenv("SPGPU_SPMV_VARIANT", str(variant))
+    g = _load(name)
+    letter, ell, hell, _ = _mats(g)
+    ph = VARIANT_PHASES[variant][letter]
+    if letter == "Z" and variant <= 2:
+        ph = {1: 2, 2: 1}[variant]   # 16-byte elements: RPL is 1 already
+    for beta in (0.0, g["beta"][()] if g["beta"][()] != 0 else 0.5):
+        y = g["y"] if beta != 0 else None
+        z = _run(gpu, formats.DeviceHell(hell), g["x"], y, g["alpha"][()], beta)
+        assert z.tobytes() == O.hell_spmv(hell, g["x"], y, g["alpha"][()], beta, phases=ph).tobytes()
+        z = _run(gpu, formats.DeviceEll(ell), g["x"], y, g["alpha"][()], beta)
+        assert z.tobytes() == O.ell_spmv(ell, g["x"], y, g["alpha"][()], beta, phases=ph).tobytes()
+
+
+@pytest.mark.parametrize("name", ["powerlaw_d_b1_h64", "powerlaw_s_b0_h32", "powerlaw_z_b0_h32"])
+def test_row_reorder_in_place_and_beta_zero_ignores_y(gpu, name):
+    import torch
+    from spgpu_amd import formats
+    g = _load(name)
+    letter, ell, hell, _ = _mats(g)
+    ph = WIDE_PHASES[letter]
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(hell["rows"]).astype(np.int32)
+    alpha, beta = g["alpha"][()], (0.5 if letter in "SD" else 0.5 - 0.25j)
+
+    # rIdx: row r of the storage is row rIdx[r] of y and z (hell_spmv_base_template.cuh:227-252)
+    z = _run(gpu, formats.DeviceHell(hell, r_idx=perm), g["x"], g["y"], alpha, beta)
+    assert z.tobytes() == O.hell_spmv(hell, g["x"], g["y"], alpha, beta, r_idx=perm, phases=ph).tobytes()
+    z = _run(gpu, formats.DeviceEll(ell, r_idx=perm), g["x"], g["y"], alpha, beta)
+    assert z.tobytes() == O.ell_spmv(ell, g["x"], g["y"], alpha, beta, r_idx=perm, phases=ph).tobytes()
+
+    # z may alias y exactly (hell.h:30)
+    z = _run(gpu, formats.DeviceHell(hell), g["x"], g["y"], alpha, beta, in_place=True)
+    assert z.tobytes() == O.hell_spmv(hell, g["x"], g["y"], alpha, beta, phases=ph).tobytes()
+
+    # beta == 0 must not read y: NaN-filled y may not leak into z
+    mat = formats.DeviceHell(hell)
+    dx = formats.to_device(g["x"])
+    dy = torch.full((hell["rows"],), float("nan"), dtype=dx.dtype, device="cuda:0")
+    dz = torch.empty_like(dy)
+    mat.spmv(gpu, dz, dy, alpha, dx, 0.0)
+    torch.cuda.synchronize()
+    assert dz.cpu().numpy().tobytes() == O.hell_spmv(hell, g["x"], None, alpha, 0.0, phases=ph).tobytes()
+
+
+def test_unaligned_streams_take_the_narrow_kernel(gpu):
+    """cM / rP / z offset by one element from a 16-byte boundary: results must not change."""
+    import torch
+    from spgpu_amd import capi, formats
+    g = _load("powerlaw_d_b0_h32")
+    letter, ell, hell, _ = _mats(g)
+    want = O.hell_spmv(hell, g["x"], g["y"], 1.0, 0.5, phases=2)  # narrow slab kernel: 2 phases
+
+    def shifted(a):
+        t = torch.empty(a.size + 1, dtype=torch.from_numpy(a[:1].copy()).dtype, device="cuda:0")
+        t[1:] = torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+        return t[1:]
+
+    cM, rP = shifted(hell["values"]), shifted(hell["indices"])
+    ho, rS = formats.to_device(hell["hack_offsets"]), formats.to_device(hell["row_lengths"])
+    x, y = formats.to_device(g["x"]), shifted(g["y"])
+    z = shifted(np.zeros(hell["rows"]))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    capi.hellspmv["D"](gpu, p(z), p(y), 1.0, p(cM), p(rP), 32, p(ho), p(rS), None, 0, hell["rows"], p(x), 0.5, 0)
+    torch.cuda.synchronize()
+    assert z.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_degenerate_shapes(gpu):
+    import torch
+    from spgpu_amd import formats
+    # no entries at all: z = beta*y (alpha*0), and beta == 0 gives zeros
+    g = _load("empty_d")
+    _, ell, hell, hdia = _mats(g)
+    y = np.linspace(-1, 1, 40)
+    x = np.ones(40)
+    for mat, orc in ((formats.DeviceHell(hell), lambda yy, b: O.hell_spmv(hell, x, yy, 2.0, b)),
+                     (formats.DeviceEll(ell), lambda yy, b: O.ell_spmv(ell, x, yy, 2.0, b)),
+                     (formats.DeviceHdia(hdia), lambda yy, b: O.hdia_spmv(hdia, x, yy, 2.0, b))):
+        assert np.array_equal(_run(gpu, mat, x, y, 2.0, -0.5), orc(y, -0.5))
+        assert np.array_equal(_run(gpu, mat, x, None, 2.0, 0.0), np.zeros(40))
+    # a single row, double complex
+    g = _load("onerow_z")
+    _, ell, hell, hdia = _mats(g)
+    x = (np.arange(5) + 1j * np.arange(5)[::-1]).astype(np.complex128)
+    want = O.hell_spmv(hell, x, None, 1.0, 0.0, phases=2)
+    assert _run(gpu, formats.DeviceHell(hell), x, None, 1.0, 0.0).tobytes() == want.tobytes()
+    assert _run(gpu, formats.DeviceEll(ell), x, None, 1.0, 0.0).tobytes() == want.tobytes()
+    assert _run(gpu, formats.DeviceHdia(hdia), x, None, 1.0, 0.0).tobytes() == O.hdia_spmv(hdia, x, None, 1.0, 0.0).tobytes()
+    # rows == 0 is a no-op
+    from spgpu_amd import capi
+    capi.hellspmv["D"](gpu, None, None, 1.0, None, None, 32, None, None, None, 0, 0, None, 0.0, 0)
+    torch.cuda.synchronize()
+
+
+def test_ctest_program(gpu):
+    """The reference's ctest.c:105-149 sequence: ELL then HELL, alpha 2, beta -3, dot(z,z) printed."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n, m, r, c, v = synth.ctest_matrix(np.float32)
+    ell = formats.coo_to_ell(n, r, c, v)
+    hell = formats.ell_to_hell(ell, 32)
+    g = _load("ctest_s")
+    dx, dy = formats.to_device(g["x"]), formats.to_device(g["y"])
+    dz = torch.empty_like(dy)
+    dots = []
+    for mat in (formats.DeviceEll(ell), formats.DeviceHell(hell)):
+        mat.spmv(gpu, dz, dy, 2.0, dx, -3.0, avg_nnz=ell["max_row"])
+        dots.append(capi.dot["S"](gpu, n, C.c_void_p(dz.data_ptr()), C.c_void_p(dz.data_ptr())))
+        want = 4.0 * g["x"].astype(np.float64) - 3.0 * g["y"].astype(np.float64)
+        assert np.max(np.abs(dz.cpu().numpy() - want)) <= 1e-5
+    assert dots[0] == dots[1]
+    assert abs(dots[0] - float(np.sum(want * want))) <= 1e-4 * float(np.sum(want * want))
+
+
+def test_handle_and_streams(gpu):
+    """core.c:11-80 behaviour: device properties cached, SetStream(0) restores the default stream."""
+    import torch
+    from spgpu_amd import capi
+    h = gpu.contents
+    assert h.warpSize == 64 and h.multiProcessorCount >= 1 and h.maxThreadsPerBlock == 1024
+    assert h.currentStream == h.defaultStream and h.defaultStream
+    s = C.c_void_p()
+    capi.spgpuStreamCreate(gpu, C.byref(s))
+    assert s.value
+    capi.spgpuSetStream(gpu, s)
+    assert capi.spgpuGetStream(gpu) == s.value
+    capi.spgpuSetStream(gpu, None)
+    assert capi.spgpuGetStream(gpu) == gpu.contents.defaultStream
+    capi.spgpuStreamDestroy(s)
+    # a torch stream can carry the library's work
+    ts = torch.cuda.Stream()
+    capi.spgpuSetStream(gpu, C.c_void_p(ts.cuda_stream))
+    a = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+    z = torch.empty_like(a)
+    with torch.cuda.stream(ts):
+        capi.axpby["D"](gpu, C.c_void_p(z.data_ptr()), 1000, 0.0, None, 2.0, C.c_void_p(a.data_ptr()))
+    ts.synchronize()
+    assert torch.equal(z, 2.0 * a)
+    capi.spgpuSetStream(gpu, None)
