@@ -20,6 +20,14 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} not found: build it with `make lib` (or __graft_entry__.build()); "
         "spgpu-amd has no Python or CPU fallback for its kernels")
 
+# torch (device-memory plumbing of the tests and bench.py) ships its own HIP runtime with the
+# same soname as /opt/rocm's; whichever is loaded first serves the whole process.  Load torch's
+# first so that the tensors it allocates and the kernels launched here share ONE runtime.
+try:
+    import torch  # noqa: F401
+except ImportError:  # a C-only deployment links /opt/rocm's runtime directly
+    pass
+
 lib = C.CDLL(LIB_PATH)
 
 # ---- types ------------------------------------------------------------------

@@ -7,6 +7,7 @@
  */
 #include "spgpu_internal.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -17,8 +18,11 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     *pHandle = NULL;
 
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+    hipError_t perr = hipGetDeviceProperties(&prop, device);
+    if (perr != hipSuccess) {
+        fprintf(stderr, "spgpuCreate: hipGetDeviceProperties(%d) failed: %s\n", device, hipGetErrorString(perr));
         return SPGPU_UNSPECIFIED;
+    }
 
     SpgpuPrivateHandle* h = (SpgpuPrivateHandle*)calloc(1, sizeof(SpgpuPrivateHandle));
     if (!h)
@@ -36,6 +40,7 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     hipSetDevice(previous);
 
     if (err != hipSuccess) {
+        fprintf(stderr, "spgpuCreate: device %d setup failed: %s\n", device, hipGetErrorString(err));
         if (h->reduceScratch) hipFree(h->reduceScratch);
         if (h->pub.defaultStream) hipStreamDestroy(h->pub.defaultStream);
         free(h);
