@@ -38,8 +38,13 @@ def parse():
                    help="column pattern of the headline workload (SURVEY 8(d) C2 defines banded and random)")
     p.add_argument("--no-extras", action="store_true", help="skip the untimed extra variants and the CPU baseline")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg")
+    p.add_argument("--workload", default="auto", choices=["auto", "spmv", "spmm"],
+                   help="auto: spmv on 1 GPU (the headline metric), row-sharded spmm on more")
     p.add_argument("--spmm-rows-per-gpu", type=int, default=5_000_000)
     p.add_argument("--rhs", type=int, default=16)
+    p.add_argument("--spmm-pattern", default="banded", choices=["banded", "random", "window"])
+    p.add_argument("--no-split", action="store_true",
+                   help="spmm: do not cut the local block by column ownership (no compute/all-gather overlap)")
     return p.parse_args()
 
 
@@ -117,6 +122,9 @@ def run_spmv(args, rank, world):
 
     def build(pattern):
         h = synth.hell_uniform_on_device(args.rows, args.nnz_per_row, pattern, "D", 32, seed=1, device=dev)
+        # torch fills these arrays on ITS stream; the library launches on the handle's stream.
+        # Without this the SpMV could read column indices that are still being written.
+        torch.cuda.synchronize()
         return h
 
     def launcher(h, x, y, z, alpha, beta):
@@ -200,6 +208,137 @@ def run_spmv(args, rank, world):
     capi.spgpuDestroy(handle)
 
 
+def run_spmm(args, rank, world):
+    """Row-sharded HELL fp64 SpMM (BASELINE configs[4]): weak scaling, 5 M rows x 32 nnz per GPU, 16 rhs;
+    one step = all-gather of the X row blocks over RCCL + the local product(s)."""
+    import torch
+    import torch.distributed as dist
+    from spgpu_amd import capi, sharded, synth
+
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(dev)
+    handle = capi.create_handle(torch.cuda.current_device())
+    stream = torch.cuda.Stream()
+    capi.spgpuSetStream(handle, C.c_void_p(stream.cuda_stream))
+
+    rows_local, k, L = args.spmm_rows_per_gpu // 32 * 32, args.rhs, args.nnz_per_row
+    n_total = rows_local * world
+    first = rank * rows_local
+    blocks = [(r * rows_local, rows_local) for r in range(world)]
+    block = synth.hell_uniform_on_device(rows_local, L, args.spmm_pattern, "D", 32, seed=11 + rank, device=dev,
+                                         n_cols=n_total, row_offset=first)
+    split = world > 1 and not args.no_split
+    if split:
+        own, rest = synth.split_uniform_hell_by_columns(block, first, rows_local)
+        del block
+        torch.cuda.empty_cache()
+    else:
+        own, rest = block, None
+    x_local = synth.device_vector(rows_local * k, "D", 21 + rank, dev).view(rows_local, k)
+    y_local = synth.device_vector(rows_local * k, "D", 31 + rank, dev).view(rows_local, k)
+    z_local = torch.empty_like(y_local)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def local_product(part, Z, Y, alpha, X, beta):
+        capi.hellspmm["D"](handle, p(Z), p(Y), C.c_double(alpha), p(part["cM"]), p(part["rP"]), 32, p(part["hack_offsets"]),
+                           p(part["rS"]), None, L, part["rows"], p(X), C.c_double(beta), 0, k, k, k)
+
+    op = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product,
+                             lambda rows: torch.empty(rows, k, dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+
+    def step():
+        op.step(z_local, y_local, 1.0, x_local, 0.0)
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        for _ in range(args.steps):
+            step()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # untimed: the local product alone (X already gathered) and the all-gather alone
+    def timed(fn, reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            fn()
+            a.record(stream)
+            for _ in range(reps):
+                fn()
+            b.record(stream)
+        b.synchronize()
+        return a.elapsed_time(b) / reps * 1e-3
+
+    def products_only():
+        if rest is None:
+            local_product(own, z_local, y_local, 1.0, op.x_full, 0.0)
+        else:
+            local_product(own, z_local, y_local, 1.0, x_local, 0.0)
+            local_product(rest, z_local, z_local, 1.0, op.x_full, 1.0)
+
+    def gather_only():
+        w = op.gather_x(x_local, async_op=False)
+        if w is not None:
+            w.wait()
+
+    t_compute = timed(products_only, 10)
+    t_gather = timed(gather_only, 10) if world > 1 else 0.0
+    nnz_local = rows_local * L
+    hacks = rows_local // 32
+    alg = hell_algorithmic_bytes(nnz_local, rows_local, n_total, hacks, rhs=k)
+    flops_total = 2.0 * nnz_local * k * world
+
+    if rank == 0:
+        # parity: a window of local rows against the oracle, bit for bit when the block is not split
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import numpy as np
+        import oracle_api as O
+        step()
+        torch.cuda.synchronize()
+        whole = synth.hell_uniform_on_device(rows_local, L, args.spmm_pattern, "D", 32, seed=11 + rank, device=dev,
+                                             n_cols=n_total, row_offset=first) if split else own
+        torch.cuda.synchronize()
+        sub = synth.hell_rows_to_host(whole, 0, 1024)
+        want = O.hell_spmm(sub, op.x_full.cpu().numpy(), None, 1.0, 0.0)
+        got = z_local[:1024].cpu().numpy()
+        if split:
+            ok = np.max(np.abs(got - want) / (np.abs(want) + 1.0)) <= 1e-12
+            parity = "within 1e-12 of oracle on 1024 rows (own+rest regroup the sums)" if ok else "MISMATCH"
+        else:
+            parity = "bit-exact vs oracle on 1024 rows" if got.tobytes() == want.tobytes() else "MISMATCH"
+        out = dict(
+            metric="HELL fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), 1 GPU",
+            value=round(flops_total * args.steps / wall * 1e-9, 2), unit="GFLOP/s", n_gpus=world, steps=args.steps,
+            warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 5), higher_is_better=True, scaling="weak",
+            vs_baseline=None, dtype="f64", data="synthetic",
+            config=dict(workload=f"row-sharded HELL fp64 SpMM (spgpuDhellspmm), {rows_local} rows/GPU x {L} nnz/row x {k} rhs, "
+                                 f"{n_total} rows total, columns {args.spmm_pattern}, RCCL all-gather(X) per step "
+                                 f"(BASELINE configs[4] at 8 GPUs)",
+                        rows_per_gpu=rows_local, rows_total=n_total, rhs=k, pattern=args.spmm_pattern,
+                        parallelism=f"row partition x{world}, all-gather of X" + (", own/rest column split (overlap)" if split else "")),
+            roofline=dict(bound="hbm", achieved=round(alg / t_compute * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                          frac=round(alg / t_compute * 1e-9 / HBM_PEAK_GBS, 4), traffic=None, kernel="hellSpmmKernel<double,16>",
+                          algorithmic_bytes_per_launch=alg, kernel_ms=round(t_compute * 1e3, 4)),
+            spmm=dict(compute_only_ms=round(t_compute * 1e3, 4), allgather_only_ms=round(t_gather * 1e3, 4),
+                      compute_only_gflops_total=round(flops_total / t_compute * 1e-9, 1),
+                      allgather_GBps_per_rank=round((world - 1) * rows_local * k * 8 / t_gather * 1e-9, 1) if t_gather else None),
+            parity=parity, cpu_baseline=None)
+        print(json.dumps(out), flush=True)
+    capi.spgpuDestroy(handle)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -210,8 +349,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         dist.init_process_group("nccl")
+    workload = args.workload if args.workload != "auto" else ("spmv" if world == 1 else "spmm")
     try:
-        run_spmv(args, rank, world)
+        (run_spmv if workload == "spmv" else run_spmm)(args, rank, world)
     finally:
         if world > 1:
             import torch.distributed as dist

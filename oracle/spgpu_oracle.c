@@ -11,8 +11,10 @@
  *  - Format conversions (orc_cooToEll, orc_ellToHell, orc_cooToHdia, ...):
  *    PINNED bit-exact against the reference's own converters, compiled from
  *    /root/reference into oracle/_ref (see oracle/Makefile) and compared on
- *    randomised inputs (tests/test_oracle_vs_reference.py), and against the
- *    known-answer checksums of SURVEY.md section 8(a) (tests/golden/).
+ *    randomised inputs (tests/test_oracle_vs_reference.py), against fixtures that
+ *    build produced (tests/golden/*.npz, oracle/make_golden.py) and against the
+ *    structural known answers of SURVEY.md section 8(a) (pitch, heights, hack
+ *    offsets, diagonal sets; tests/test_oracle_golden.py).
  *  - SpMV / axpby / dot values: the reference has NO CPU implementation of
  *    these kernels and NO golden output values (its tests print dot(z,z) and a
  *    human compares formats).  Absolute values are therefore "parity
@@ -20,7 +22,8 @@
  *    analytic identity the reference's ctest.c implies (A = 2I, alpha = 2,
  *    beta = -3  =>  z = 4x - 3y), by the cross-format equalities its perf
  *    tests rely on (ELL == HELL == HDIA results), and by an independent
- *    extended-precision CSR product (tests/test_oracle_spmv.py).
+ *    extended-precision product computed from the COO triplets
+ *    (oracle/make_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py).
  *
  * Every routine exists in four flavours generated from one macro body:
  * s (float), d (double), c (float complex), z (double complex).
@@ -497,14 +500,42 @@ void orc_zaxpby(orc_cdouble* z, int n, orc_cdouble beta, const orc_cdouble* y, o
         z[i] = z_nz(beta) ? z_fma(alpha, x[i], z_mul(beta, y[i])) : z_mul(alpha, x[i]);
 }
 
-/* Multi-vector SpMM oracle for the row-sharded path (new; not in the
- * reference): column j of X/Y/Z is an independent HELL SpMV, vector j at
- * base + j*pitch (the reference's multivector convention, vector.h:75-91). */
-void orc_dhellspmm(double* Z, const double* Y, double alpha, const double* cM, const int* rP, int hackSize,
-                   const int* hackOffsets, const int* rS, const int* rIdx, int rows, const double* X, double beta,
-                   int baseIndex, int count, int xPitch, int yzPitch, int phases)
+/* Multi-vector SpMM oracle for the row-sharded path (NEW operation, not in the
+ * reference; include/spgpu/spmm.h).  Interleaved multivectors: element j of row i
+ * at M[i*ld + j].  Per (row, rhs): products added in ascending k -- the order of
+ * the reference's one-thread-per-row HELL kernel (hell_spmv_base_template.cuh:197-214)
+ * -- then the usual epilogue (:219-222). */
+#define ORC_DEFINE_SPMM(P, T)                                                                                 \
+    void orc_##P##hellspmm(T* Z, const T* Y, T alpha, const T* cM, const int* rP, int hackSize,               \
+                           const int* hackOffsets, const int* rS, const int* rIdx, int rows, const T* X,      \
+                           T beta, int baseIndex, int count, int ldX, int ldYZ)                               \
+    {                                                                                                         \
+        _Pragma("omp parallel for schedule(static)")                                                          \
+        for (int i = 0; i < rows; ++i) {                                                                      \
+            const size_t slot0 = (size_t)hackOffsets[i / hackSize] + (size_t)(i % hackSize);                  \
+            const size_t out = (size_t)(rIdx ? rIdx[i] : i) * (size_t)ldYZ;                                   \
+            for (int j = 0; j < count; ++j) {                                                                 \
+                T sum = P##_zero();                                                                           \
+                for (int k = 0; k < rS[i]; ++k) {                                                             \
+                    const size_t s = slot0 + (size_t)k * (size_t)hackSize;                                    \
+                    sum = P##_fma(cM[s], X[(size_t)(rP[s] - baseIndex) * (size_t)ldX + j], sum);              \
+                }                                                                                             \
+                if (P##_nz(beta))                                                                             \
+                    Z[out + j] = P##_fma(beta, Y[out + j], P##_mul(alpha, sum));                              \
+                else                                                                                          \
+                    Z[out + j] = P##_mul(alpha, sum);                                                         \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+ORC_DEFINE_SPMM(s, float)
+ORC_DEFINE_SPMM(d, double)
+
+void orc_set_threads(int n)
 {
-    for (int j = 0; j < count; ++j)
-        orc_dhellspmv(Z + (size_t)j * yzPitch, Y ? Y + (size_t)j * yzPitch : NULL, alpha, cM, rP, hackSize, hackOffsets,
-                      rS, rIdx, rows, X + (size_t)j * xPitch, beta, baseIndex, phases);
+#ifdef _OPENMP
+    if (n > 0)
+        omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }

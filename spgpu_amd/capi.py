@@ -113,6 +113,15 @@ for _L, _T in SCALAR.items():
     nrm2[_L] = _decl(f"spgpu{_L}nrm2", REAL[_L], [Handle, i32, ptr])
     mnrm2[_L] = _decl(f"spgpu{_L}mnrm2", None, [Handle, ptr, i32, ptr, i32, i32])
 
+# ---- spmm.h (new: multi-vector product of the row-sharded path) ---------------------
+hellspmm, mv_interleave, mv_deinterleave = {}, {}, {}
+for _L in "SD":
+    _T = SCALAR[_L]
+    hellspmm[_L] = _decl(f"spgpu{_L}hellspmm", None,
+                         [Handle, ptr, ptr, _T, ptr, ptr, i32, ptr, ptr, ptr, i32, i32, ptr, _T, i32, i32, i32, i32])
+    mv_interleave[_L] = _decl(f"spgpu{_L}mvInterleave", None, [Handle, ptr, i32, ptr, i32, i32, i32])
+    mv_deinterleave[_L] = _decl(f"spgpu{_L}mvDeinterleave", None, [Handle, ptr, i32, ptr, i32, i32, i32])
+
 # ---- ell_conv.h / hell_conv.h / hdia_conv.h (host pointers) --------------------------
 computeEllRowLenghts = _decl("computeEllRowLenghts", None, [ptr, C.POINTER(i32), i32, i32, ptr, i32])
 computeEllAllocPitch = _decl("computeEllAllocPitch", i32, [i32])

@@ -1,0 +1,114 @@
+"""Row-sharded HELL SpMM across the GPUs of one node (BASELINE configs[4]).
+
+Rows of Z = alpha*A*X + beta*Y are independent: A, Y and Z are partitioned by contiguous,
+hack-aligned row blocks, one block per rank (one process per GPU); only the dense X is needed
+everywhere, so a step is ONE exchange -- an all-gather of the ranks' X row blocks over RCCL
+(`torch.distributed`, backend "nccl" on GPUs, "gloo" in the CPU tests) -- followed by the local
+`spgpu?hellspmm`.  Interleaved multivectors make each rank's X block one contiguous buffer.
+
+Overlap: with `split=True` a rank's block of A is cut by column ownership into A_own (columns it
+already holds) and A_rest; A_own * X_own runs on the compute stream while the all-gather is in
+flight on the communication stream, then A_rest * X_full is accumulated (beta = 1, Z aliasing Y).
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-gather in which every rank sends its
+block to its 7 peers uses all links at once; per link it moves one block.
+
+Nothing here computes on the CPU: `local_product` is injected (the C ABI on GPUs, the oracle in
+the gloo test).
+"""
+import numpy as np
+
+
+def partition_rows(n_rows, world, hack_size=32):
+    """Contiguous row blocks, boundaries multiples of hack_size, sizes as equal as hacks allow.
+    Returns [(first_row, n_rows_in_block)] * world."""
+    hacks = (n_rows + hack_size - 1) // hack_size
+    base, extra = divmod(hacks, world)
+    out, first = [], 0
+    for r in range(world):
+        h = base + (1 if r < extra else 0)
+        rows = min(h * hack_size, n_rows - first)
+        out.append((first, max(rows, 0)))
+        first += max(rows, 0)
+    return out
+
+
+def shard_hell(hell, first_row, n_rows):
+    """Rows [first_row, first_row + n_rows) of a host HELL dict as a HELL dict of their own.
+    A hack-aligned block is a contiguous piece of cM / rP; its hackOffsets are the global ones minus
+    the first (the reference's own chunk loop advances hackOffsets the same way,
+    hell_spmv_base.cuh:139-144).  hackOffsets has no trailing total (hell.c:64,75): the end of the
+    last hack is the next block's first offset or the end of the arrays."""
+    hs = hell["hack_size"]
+    assert first_row % hs == 0
+    h0 = first_row // hs
+    h1 = (first_row + n_rows + hs - 1) // hs
+    ho = np.asarray(hell["hack_offsets"], dtype=np.int64)
+    s0 = int(ho[h0]) if h0 < ho.size else int(hell["values"].size)
+    s1 = int(ho[h1]) if h1 < ho.size else int(hell["values"].size)
+    return dict(letter=hell["letter"], rows=n_rows, values=hell["values"][s0:s1], indices=hell["indices"][s0:s1],
+                hack_offsets=(ho[h0:h1] - s0).astype(np.int32), hack_size=hs,
+                row_lengths=np.asarray(hell["row_lengths"][first_row:first_row + n_rows], dtype=np.int32),
+                base=hell["base"])
+
+
+def split_by_column_owner(coo_rows, coo_cols, coo_vals, col_first, col_count, base=0):
+    """COO entries of a row block -> (own, rest): entries whose column lies in
+    [col_first, col_first + col_count) and the others, COO order kept in both."""
+    c0 = np.asarray(coo_cols, dtype=np.int64) - base
+    own = (c0 >= col_first) & (c0 < col_first + col_count)
+    pick = lambda m: (np.asarray(coo_rows)[m], np.asarray(coo_cols)[m], np.asarray(coo_vals)[m])
+    return pick(own), pick(~own)
+
+
+class ShardedSpmm:
+    """One rank's state for the sharded product.
+
+    local_product(part, Z, Y, alpha, X, beta) must compute Z = alpha*part*X + beta*Y for the HELL
+    block `part` (whatever object the caller built: a device-resident matrix for the C ABI, a host
+    dict for the oracle) with interleaved X / Y / Z.
+    """
+
+    def __init__(self, dist, rank, world, col_blocks, own, rest, local_product, new_full_x, comm_stream=None):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.col_blocks = col_blocks                  # [(first, count)] ownership of X rows per rank
+        self.own, self.rest = own, rest               # rest is None when the block is not split
+        self.local_product = local_product
+        self.x_full = new_full_x(sum(c for _, c in col_blocks))
+        self.comm_stream = comm_stream
+        counts = {c for _, c in col_blocks}
+        self.equal_blocks = len(counts) == 1
+
+    def gather_x(self, x_local, async_op=False):
+        """All-gather of the X row blocks into x_full (rows in rank order)."""
+        if self.world == 1:
+            self.x_full[: x_local.shape[0]].copy_(x_local)
+            return None
+        if self.equal_blocks:
+            return self.dist.all_gather_into_tensor(self.x_full, x_local, async_op=async_op)
+        # unequal blocks: pad every contribution to the largest block
+        big = max(c for _, c in self.col_blocks)
+        import torch
+        pad = torch.zeros((big,) + tuple(x_local.shape[1:]), dtype=x_local.dtype, device=x_local.device)
+        pad[: x_local.shape[0]].copy_(x_local)
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        work = self.dist.all_gather(parts, pad, async_op=async_op)
+        if work is not None:
+            work.wait()
+        for (first, count), p in zip(self.col_blocks, parts):
+            self.x_full[first:first + count].copy_(p[:count])
+        return None
+
+    def step(self, z_local, y_local, alpha, x_local, beta):
+        """One sharded product.  With a split block the own-column part overlaps the all-gather."""
+        if self.rest is None:
+            work = self.gather_x(x_local)
+            if work is not None:
+                work.wait()
+            self.local_product(self.own, z_local, y_local, alpha, self.x_full, beta)
+            return
+        work = self.gather_x(x_local, async_op=True)
+        # columns of `own` are indexed relative to this rank's X block
+        self.local_product(self.own, z_local, y_local, alpha, x_local, beta)
+        if work is not None:
+            work.wait()
+        self.local_product(self.rest, z_local, z_local, alpha, self.x_full, 1.0)

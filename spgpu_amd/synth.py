@@ -127,7 +127,7 @@ def banded_coo(n, half_width=16, letter="D", seed=2, base=0):
 # ---- device-side generators for the BASELINE-size workloads (torch is plumbing) --------
 
 def hell_uniform_on_device(n_rows, nnz_per_row, pattern="random", letter="D", hack_size=32, seed=1,
-                           device="cuda:0", n_cols=None, band_offset=None):
+                           device="cuda:0", n_cols=None, band_offset=None, row_offset=0):
     """A HELL matrix with exactly `nnz_per_row` entries in every row, built directly in HBM
     (BASELINE config 2: 10 M rows x 32).  With a uniform row length L the HELL arrays of
     hell.c:46-104 are a dense [hacks][L][hack_size] block: slot(r, k) = (r // hs)*hs*L + r % hs + k*hs.
@@ -147,8 +147,9 @@ def hell_uniform_on_device(n_rows, nnz_per_row, pattern="random", letter="D", ha
     tdt = {"S": torch.float32, "D": torch.float64, "C": torch.complex64, "Z": torch.complex128}[letter]
     rdt = {"S": torch.float32, "D": torch.float64, "C": torch.float32, "Z": torch.float64}[letter]
 
+    # global row number of every slot; row_offset != 0 builds a row BLOCK of a larger matrix
     row = (torch.arange(hacks, device=device, dtype=torch.int64)[:, None, None] * hs
-           + torch.arange(hs, device=device, dtype=torch.int64)[None, None, :])          # [hacks,1,hs]
+           + torch.arange(hs, device=device, dtype=torch.int64)[None, None, :] + row_offset)  # [hacks,1,hs]
     if pattern == "banded":
         k = torch.arange(L, device=device, dtype=torch.int64)[None, :, None]
         cols = (row + k - (L // 2 if band_offset is None else band_offset)) % n_cols
@@ -199,3 +200,35 @@ def hell_rows_to_host(h, first_row, n_rows):
     return dict(letter=h["letter"], rows=n_rows, values=h["cM"][s0:s1].cpu().numpy(),
                 indices=h["rP"][s0:s1].cpu().numpy(), hack_offsets=ho.astype(np.int32), hack_size=hs,
                 row_lengths=h["rS"][first_row:first_row + n_rows].cpu().numpy(), base=h["base"])
+
+
+def split_uniform_hell_by_columns(h, col_first, col_count):
+    """Cut a uniform device HELL block (from hell_uniform_on_device) by column ownership into
+    (own, rest): `own` keeps the entries whose column is in [col_first, col_first+col_count), with
+    columns rebased to that block; `rest` keeps the others with global columns.  Entries keep their
+    order within a row; both results are ragged HELL matrices built as hell.c:46-104 lays them out
+    (per hack: hackSize * longest row slots, padding zero)."""
+    import torch
+    hs, L, rows = h["hack_size"], h["row_len"], h["rows"]
+    hacks = rows // hs
+    cols = h["rP"].view(hacks, L, hs).to(torch.int64)
+    vals = h["cM"].view(hacks, L, hs)
+    own_mask = (cols >= col_first) & (cols < col_first + col_count)
+
+    def compact(mask, col_shift):
+        lengths = mask.sum(dim=1)                                   # [hacks, hs]
+        depth = lengths.max(dim=1).values                           # [hacks]
+        hack_offsets = torch.cumsum(depth * hs, 0) - depth * hs     # exclusive prefix
+        total = int((depth * hs).sum().item())
+        pos = torch.cumsum(mask.to(torch.int64), dim=1) - 1         # k-position among kept entries
+        lane = torch.arange(hs, device=cols.device, dtype=torch.int64)[None, None, :]
+        dst = (hack_offsets[:, None, None] + lane + pos * hs)[mask]
+        cM = torch.zeros(max(total, 1), dtype=vals.dtype, device=cols.device)
+        rP = torch.zeros(max(total, 1), dtype=torch.int32, device=cols.device)
+        cM[dst] = vals[mask]
+        rP[dst] = (cols[mask] - col_shift).to(torch.int32)
+        return dict(letter=h["letter"], rows=rows, cols=h["cols"], hack_size=hs, nnz=int(mask.sum().item()),
+                    cM=cM, rP=rP, hack_offsets=hack_offsets.to(torch.int32),
+                    rS=lengths.reshape(-1).to(torch.int32).contiguous(), base=0, slots=total)
+
+    return compact(own_mask, col_first), compact(~own_mask, 0)

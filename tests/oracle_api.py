@@ -227,3 +227,25 @@ def nrm2(letter, a):
     a = np.ascontiguousarray(a, NP_DTYPE[letter])
     getattr(orc, f"orc_{_LOW[letter]}nrm2")(_p(out), a.size, _p(a))
     return out[0]
+
+
+orc.orc_set_threads.argtypes = [i32]
+orc.orc_threads.restype = i32
+for _L in "SD":
+    _f = getattr(orc, f"orc_{_LOW[_L]}hellspmm")
+    _f.restype = None
+    _f.argtypes = [ptr, ptr, SCALAR[_L], ptr, ptr, i32, ptr, ptr, ptr, i32, ptr, SCALAR[_L], i32, i32, i32, i32]
+
+
+def hell_spmm(hell, X, Y, alpha, beta, r_idx=None):
+    """Interleaved multivectors: X is [cols, count], Y/Z are [rows, count] (C-contiguous)."""
+    L = hell["letter"]
+    X = np.ascontiguousarray(X, NP_DTYPE[L])
+    count = X.shape[1]
+    Z = np.zeros((hell["rows"], count), NP_DTYPE[L]) if Y is None else np.array(Y, NP_DTYPE[L], copy=True, order="C")
+    YY = None if Y is None else np.ascontiguousarray(Y, NP_DTYPE[L])
+    ri = None if r_idx is None else np.ascontiguousarray(r_idx, np.int32)
+    getattr(orc, f"orc_{_LOW[L]}hellspmm")(_p(Z), _p(YY), scalar(L, alpha), _p(hell["values"]), _p(hell["indices"]),
+                                           hell["hack_size"], _p(hell["hack_offsets"]), _p(hell["row_lengths"]), _p(ri),
+                                           hell["rows"], _p(X), scalar(L, beta), hell["base"], count, count, count)
+    return Z

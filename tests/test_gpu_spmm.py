@@ -1,0 +1,90 @@
+"""GPU: spgpu?hellspmm (new multi-vector product of the row-sharded path) against the oracle,
+bit for bit (per (row, rhs) the kernel adds in ascending k, as the oracle does), plus the
+multivector layout converters."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _hell(name):
+    with np.load(os.path.join(GOLD, name + ".npz")) as f:
+        g = {k: f[k] for k in f.files}
+    letter = O.LETTER_OF[g["coo_vals"].dtype]
+    hell = dict(letter=letter, rows=int(g["n_rows"]), values=g["hell_values"], indices=g["hell_indices"],
+                hack_offsets=g["hell_hack_offsets"], hack_size=int(g["hack_size"]), row_lengths=g["row_lengths"],
+                base=int(g["base"]), height=int(g["hell_height"]))
+    return g, letter, hell
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("count", [1, 3, 4, 7, 8, 16, 21, 32])
+@pytest.mark.parametrize("name", ["powerlaw_d_b0_h32", "powerlaw_s_b1_h64", "lap3d_16_d", "ctest_s"])
+def test_spmm_matches_oracle(gpu, name, count):
+    import torch
+    from spgpu_amd import capi, formats, synth
+    g, letter, hell = _hell(name)
+    n_cols = int(g["n_cols"])
+    X = synth.values_for(letter, 100 + count, n_cols * count).reshape(n_cols, count)
+    Y = synth.values_for(letter, 200 + count, hell["rows"] * count).reshape(hell["rows"], count)
+    mat = formats.DeviceHell(hell)
+    dX, dY = formats.to_device(X), formats.to_device(Y)
+    for beta in (0.0, -0.5):
+        dZ = torch.full_like(dY, float("nan"))
+        capi.hellspmm[letter](gpu, _p(dZ), _p(dY), capi.scalar(letter, 1.25), _p(mat.cM), _p(mat.rP), mat.hack_size,
+                              _p(mat.hack_offsets), _p(mat.rS), None, 0, mat.rows, _p(dX), capi.scalar(letter, beta),
+                              mat.base, count, count, count)
+        torch.cuda.synchronize()
+        want = O.hell_spmm(hell, X, Y if beta != 0 else None, 1.25, beta)
+        assert dZ.cpu().numpy().tobytes() == want.tobytes()
+    # every column of the product equals the single-vector SpMV in reference order
+    z0 = O.hell_spmv(hell, np.ascontiguousarray(X[:, 0]), None, 1.25, 0.0, phases=1)
+    assert np.array_equal(O.hell_spmm(hell, X, None, 1.25, 0.0)[:, 0], z0)
+
+
+def test_spmm_leading_dimensions_row_reorder_and_in_place(gpu):
+    import torch
+    from spgpu_amd import capi, formats, synth
+    g, letter, hell = _hell("powerlaw_d_b1_h64")
+    n_cols, rows, count, ldx, ldz = int(g["n_cols"]), hell["rows"], 6, 9, 8
+    Xp = synth.values_for("D", 1, n_cols * ldx).reshape(n_cols, ldx)
+    Yp = synth.values_for("D", 2, rows * ldz).reshape(rows, ldz)
+    perm = np.random.default_rng(4).permutation(rows).astype(np.int32)
+    mat = formats.DeviceHell(hell, r_idx=perm)
+    dX, dZ = formats.to_device(Xp), formats.to_device(Yp)   # Z aliases Y
+    capi.hellspmm["D"](gpu, _p(dZ), _p(dZ), 2.0, _p(mat.cM), _p(mat.rP), mat.hack_size, _p(mat.hack_offsets), _p(mat.rS),
+                       _p(mat.rIdx), 0, rows, _p(dX), 0.75, mat.base, count, ldx, ldz)
+    torch.cuda.synchronize()
+    got = dZ.cpu().numpy()
+    want = O.hell_spmm(hell, np.ascontiguousarray(Xp[:, :count]), np.ascontiguousarray(Yp[:, :count]), 2.0, 0.75, r_idx=perm)
+    assert got[:, :count].tobytes() == want.tobytes()
+    assert np.array_equal(got[:, count:], Yp[:, count:])   # padding columns of Z untouched
+
+
+@pytest.mark.parametrize("letter", "SD")
+def test_multivector_layout_converters(gpu, letter):
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n, count, pitch, ld = 1003, 5, 1024, 7
+    src = synth.values_for(letter, 9, count * pitch)
+    d_src = formats.to_device(src)
+    inter = torch.zeros(n * ld, dtype=d_src.dtype, device="cuda:0")
+    capi.mv_interleave[letter](gpu, _p(inter), ld, _p(d_src), pitch, n, count)
+    back = torch.zeros_like(d_src)
+    capi.mv_deinterleave[letter](gpu, _p(back), pitch, _p(inter), ld, n, count)
+    torch.cuda.synchronize()
+    got = inter.cpu().numpy().reshape(n, ld)
+    for j in range(count):
+        assert np.array_equal(got[:, j], src[j * pitch:j * pitch + n])
+        assert np.array_equal(back.cpu().numpy()[j * pitch:j * pitch + n], src[j * pitch:j * pitch + n])
+    assert not np.any(got[:, count:])

@@ -23,6 +23,7 @@ for pattern in patterns:
     h = synth.hell_uniform_on_device(rows, L, pattern, letter, 32, seed=1)
     x, y = synth.device_vector(rows, letter, 3), synth.device_vector(rows, letter, 4)
     z = torch.empty_like(y)
+    torch.cuda.synchronize()  # inputs are produced on torch's stream, consumed on the handle's
     alg = h["nnz"] * (elem + 4) + rows * (4 + elem) + rows * elem + rows // 32 * 4
     one, zero = capi.scalar(letter, 1.0), capi.scalar(letter, 0.0)
     call = lambda: capi.hellspmv[letter](handle, p(z), p(y), one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]),
