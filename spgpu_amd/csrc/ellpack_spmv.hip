@@ -80,7 +80,7 @@ constexpr int kWavesPerBlock = kBlockThreads / kWave;
  * UNROLL slab-column loads issued back to back before the first gather
  * One wavefront owns 64/PH strips = (64/PH)*RPL consecutive rows.
  */
-template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL>
+template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, bool PIPE>
 __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
@@ -128,23 +128,31 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
     const int* __restrict__ idxs = a.rP + slab;
     const T* __restrict__ x = a.x;
 
-    for (int kBase = 0; kBase < groupLongest; kBase += PH * UNROLL) {
+    /* One stage = UNROLL slab columns per phase: the coefficient/index loads of a stage are
+     * issued back to back (fetch), its x gathers and multiply-adds follow (consume).  With
+     * PIPE the next stage is fetched BEFORE the current one is consumed, so the stream loads
+     * of stage s+1 are in flight while the gathers of stage s wait for x. */
+    struct Stage {
         Pack<T, RPL> v[UNROLL];
         Pack<int, RPL> c[UNROLL];
+    };
+    auto fetch = [&](int kBase, Stage& s) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = kBase + u * PH + phase;
             if (k < laneLongest) {
-                v[u] = loadPack<NT, T, RPL>(vals + (long long)k * a.valStride);
-                c[u] = loadPack<NT, int, RPL>(idxs + (long long)k * a.idxStride);
+                s.v[u] = loadPack<NT, T, RPL>(vals + (long long)k * a.valStride);
+                s.c[u] = loadPack<NT, int, RPL>(idxs + (long long)k * a.idxStride);
             } else {
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
-                    v[u].v[t] = zeroOf<T>();
-                    c[u].v[t] = a.baseIndex;
+                    s.v[u].v[t] = zeroOf<T>();
+                    s.c[u].v[t] = a.baseIndex;
                 }
             }
         }
+    };
+    auto consume = [&](int kBase, const Stage& s) {
         T xv[UNROLL][RPL];
         bool use[UNROLL][RPL];
 #pragma unroll
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
             const int k = kBase + u * PH + phase;
 #pragma unroll
             for (int t = 0; t < RPL; ++t) {
-                const int col = c[u].v[t] - a.baseIndex;
+                const int col = s.c[u].v[t] - a.baseIndex;
                 use[u][t] = k < len[t] && col >= 0;
                 xv[u][t] = x[use[u][t] ? col : 0];
             }
@@ -161,9 +169,25 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
         for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
             for (int t = 0; t < RPL; ++t) {
-                const T next = mulAdd(v[u].v[t], xv[u][t], sum[t]);
-                sum[t] = use[u][t] ? next : sum[t];
+                sum[t] = pick(use[u][t], mulAdd(s.v[u].v[t], xv[u][t], sum[t]), sum[t]);
             }
+        }
+    };
+
+    constexpr int STEP = PH * UNROLL;
+    if constexpr (PIPE) {
+        Stage cur, nxt;
+        fetch(0, cur);
+        for (int kBase = 0; kBase < groupLongest; kBase += STEP) {
+            fetch(kBase + STEP, nxt); /* lanes past their rows' end fetch nothing */
+            consume(kBase, cur);
+            cur = nxt;
+        }
+    } else {
+        for (int kBase = 0; kBase < groupLongest; kBase += STEP) {
+            Stage cur;
+            fetch(kBase, cur);
+            consume(kBase, cur);
         }
     }
 
@@ -218,17 +242,17 @@ static bool alignedTo(const void* p, size_t bytes)
     return ((uintptr_t)p % bytes) == 0;
 }
 
-template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL>
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool PIPE = false>
 static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
 {
     constexpr int GROUP_ROWS = (kWave / PH) * RPL;
     const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
     const unsigned blocks = (unsigned)((groups + kWavesPerBlock - 1) / kWavesPerBlock);
     if (nt)
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL>), dim3(blocks),
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE>), dim3(blocks),
                            dim3(kBlockThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL>), dim3(blocks),
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE>), dim3(blocks),
                            dim3(kBlockThreads), 0, stream, a);
 }
 
@@ -250,31 +274,54 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     const bool wideOk = layoutOk && alignedTo(a.cM, 16) && alignedTo(a.rP, 4 * WIDE) &&
                         a.valStride % WIDE == 0 && a.idxStride % WIDE == 0;
 
-    /* Tuning knobs (experiments only): SPGPU_SPMV_VARIANT
-     *   0 auto | 1 wide+phases | 2 wide, one lane per strip | 3 narrow+2 phases | 4 narrow, lane per row
-     * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams. */
+    /* Kernel shape.  Measured on MI355X, 10 M rows x 32 nnz, banded columns (tools/sweep_hell.py,
+     * profiles/): D/C stream fastest with a lane walking whole rows, 8 slab columns per stage
+     * and the next stage prefetched (5.93 TB/s); S with 8 phases x 2 columns, prefetched
+     * (5.44 TB/s); 16-byte elements (Z) and unaligned streams take RPL = 1 with 2 phases x 4
+     * columns, prefetched (5.93 TB/s).
+     * SPGPU_SPMV_VARIANT (experiments; 0 = this table):
+     *   1 wide PHx2 | 2 wide 1x4 | 3 narrow 2x4 | 4 narrow 1x4 | 6 wide PHx2 pipe | 12 wide 1x8 pipe | 13 narrow 2x4 pipe
+     *   (5,7..11,14..16 exist only in -DSPGPU_TUNING_VARIANTS builds)
+     * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams (default 1). */
     int variant = envInt("SPGPU_SPMV_VARIANT", 0);
     const bool nt = envInt("SPGPU_NT_LOADS", 1) != 0;
-    if (variant < 1 || variant > 4)
-        variant = wideOk ? 1 : 3;
-    if (!wideOk && variant <= 2)
-        variant += 2;
+    if (variant < 1 || variant > 16)
+        variant = !wideOk ? 13 : (sizeof(T) == 4 ? 6 : 12);
+    const bool narrowVariant = variant == 3 || variant == 4 || variant >= 13;
+    if (!wideOk && !narrowVariant)
+        variant = 13;
 
-    if (variant <= 2) {
+    if (!narrowVariant) {
         a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
         if constexpr (WIDE > 1) {
-            if (variant == 1)
-                launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2>(stream, a, nt);
-            else
-                launchSlab<T, WIDE, 1, IS_HELL, 4>(stream, a, nt);
+            switch (variant) {
+            case 1: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2>(stream, a, nt); break;
+            case 2: launchSlab<T, WIDE, 1, IS_HELL, 4>(stream, a, nt); break;
+            case 6: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true>(stream, a, nt); break;
+#ifdef SPGPU_TUNING_VARIANTS
+            case 5: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 4>(stream, a, nt); break;
+            case 7: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 4, true>(stream, a, nt); break;
+            case 8: launchSlab<T, WIDE, 1, IS_HELL, 4, true>(stream, a, nt); break;
+            case 9: launchSlab<T, WIDE, 1, IS_HELL, 8>(stream, a, nt); break;
+            case 10: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 1, true>(stream, a, nt); break;
+            case 11: launchSlab<T, WIDE, 1, IS_HELL, 2, true>(stream, a, nt); break;
+#endif
+            default: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break; /* 12 */
+            }
             return;
         }
     }
     a.wideIO = 1; /* RPL == 1: element access is always aligned */
-    if (variant == 1 || variant == 3)
-        launchSlab<T, 1, 2, IS_HELL, 4>(stream, a, nt);
-    else
-        launchSlab<T, 1, 1, IS_HELL, 4>(stream, a, nt);
+    switch (variant) {
+    case 3: launchSlab<T, 1, 2, IS_HELL, 4>(stream, a, nt); break;
+    case 4: launchSlab<T, 1, 1, IS_HELL, 4>(stream, a, nt); break;
+#ifdef SPGPU_TUNING_VARIANTS
+    case 14: launchSlab<T, 1, 1, IS_HELL, 8, true>(stream, a, nt); break;
+    case 15: launchSlab<T, 1, 2, IS_HELL, 8>(stream, a, nt); break;
+    case 16: launchSlab<T, 1, 4, IS_HELL, 2, true>(stream, a, nt); break;
+#endif
+    default: launchSlab<T, 1, 2, IS_HELL, 4, true>(stream, a, nt); break; /* 13 */
+    }
 }
 
 template <typename T, typename ApiT>

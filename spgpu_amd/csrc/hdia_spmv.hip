@@ -115,8 +115,7 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
         for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
             for (int t = 0; t < RPL; ++t) {
-                const T next = mulAdd(v[u].v[t], xv[u][t], sum[t]);
-                sum[t] = use[u][t] ? next : sum[t];
+                sum[t] = pick(use[u][t], mulAdd(v[u].v[t], xv[u][t], sum[t]), sum[t]);
             }
         }
     }

@@ -4,23 +4,24 @@
  * reference has none); A uses the HELL arguments of hell.h:45-59.
  *
  * ---- Wavefront design -------------------------------------------------------
- * KP (4, 8 or 16) lanes form a "row team": lane j of the team owns right-hand
- * side j.  A wavefront has G = 64/KP teams and owns one 32-row group of a hack;
- * team g owns rows g, g+G, g+2G, ... of the group (32/G rows), one running sum
- * per owned row in registers.
- *   for every slab column k:  for every owned row i:
- *       (coef, col) of (row, k)    -- the same address for the KP lanes of a
- *                                     team: one broadcast load; the G teams of
- *                                     the wave read G adjacent elements, and
- *                                     the inner loop over i consumes the
- *                                     32-row slab column completely before k
- *                                     advances, so every 128-B line of cM/rP
- *                                     is fetched once and then hit in L1
- *       x = X[col*ld + j]          -- KP lanes read KP consecutive values: ONE
- *                                     128-B line per nonzero for 16 doubles
- *       sum[i] = fma(coef, x, sum[i])
- * No LDS, no cross-lane traffic; the order of additions per (row, rhs) is
- * ascending k.  More than 16 right-hand sides run as passes of 16.
+ * A wavefront owns 64 consecutive rows.  Two lane roles alternate:
+ *
+ *  load role   lane l fetches coefficient and column index of (row l, slab
+ *              column k): for hackSize 32 the wave reads two whole slab columns
+ *              of two hacks -- fully coalesced, every byte of cM/rP is fetched
+ *              exactly once, UNROLL columns ahead of their use.
+ *  team role   KP lanes form a row team, G = 64/KP teams per wave; lane t of a
+ *              team owns VEC consecutive right-hand sides (KP*VEC >= count, for
+ *              16 rhs: 8 lanes x 2).  Team g owns rows g*KP .. g*KP+KP-1 of the
+ *              group and keeps one running sum per owned row and rhs.  In step
+ *              i every team takes the (coef, col) pair that lane g*KP+i loaded
+ *              -- a lane shuffle inside the team (ds_bpermute / DPP, no LDS
+ *              allocation, no barrier) -- and all its lanes read their slice of
+ *              X row `col`: the KP lanes of a team read ONE contiguous 128-byte
+ *              line (16 doubles), one wave-wide 16-byte load serves G nonzeros.
+ *
+ * Per (row, rhs) the products are added in ascending k.  More than 16
+ * right-hand sides run as passes of 16 (the matrix is re-read per pass).
  *
  * Roofline: HBM.  Algorithmic bytes: the matrix once, nnz*(sizeof(T)+4) +
  * rows*4 + hacks*4, plus count * (cols + rows*(1+[beta!=0])) * sizeof(T).
@@ -29,6 +30,8 @@
 #include "spgpu_internal.h"
 
 #include "spgpu/spmm.h"
+
+#include <stdio.h>
 
 namespace spgpu {
 
@@ -43,91 +46,135 @@ template <typename T> struct SpmmArgs {
     const int* hackOffsets;
     T alpha, beta;
     int rows, baseIndex, hackSize;
-    int count;      /* right-hand sides in this pass (<= KP) */
+    int count;      /* right-hand sides in this pass (<= KP*VEC) */
     long long ldX, ldYZ;
 };
 
 constexpr int kSpmmThreads = 256;
-constexpr int kSpmmGroupRows = 32;
 
-template <typename T, int KP, int UNROLL>
+__device__ inline float laneFrom(float v, int src) { return __shfl(v, src, kWave); }
+__device__ inline double laneFrom(double v, int src) { return __shfl(v, src, kWave); }
+__device__ inline int laneFrom(int v, int src) { return __shfl(v, src, kWave); }
+
+template <typename T, int KP, int VEC, int UNROLL>
 __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T> a)
 {
-    constexpr int G = kWave / KP;              /* row teams per wavefront */
-    constexpr int OWN = kSpmmGroupRows / G;    /* rows per team */
-
     const int lane = threadIdx.x & (kWave - 1);
     const long long group = (long long)blockIdx.x * (kSpmmThreads / kWave) + (threadIdx.x >> 6);
-    const long long groupRow0 = group * kSpmmGroupRows;
+    const long long groupRow0 = group * kWave;
     if (groupRow0 >= a.rows)
-        return;
+        return; /* whole wavefront leaves together */
 
-    const int team = lane / KP;
-    const int j = lane % KP;
-    const bool rhsLive = j < a.count;
-
-    /* hackSize is a multiple of 32 on this path, so the whole group is in one hack */
-    const unsigned g0 = (unsigned)groupRow0, hs = (unsigned)a.hackSize;
-    const unsigned hack = g0 / hs;
-    const long long slab = (long long)a.hackOffsets[hack] + (g0 - hack * hs);
-
-    int len[OWN];
-    int longest = 0;
-#pragma unroll
-    for (int i = 0; i < OWN; ++i) {
-        const long long r = groupRow0 + team + (long long)i * G;
-        len[i] = r < a.rows ? a.rS[r] : 0;
-        longest = len[i] > longest ? len[i] : longest;
+    /* ---- load role: this lane's row ---- */
+    const long long myRow = groupRow0 + lane;
+    int myLen = 0;
+    long long slab = 0;
+    if (myRow < a.rows) {
+        const unsigned r = (unsigned)myRow, hs = (unsigned)a.hackSize;
+        const unsigned hack = r / hs;
+        slab = (long long)a.hackOffsets[hack] + (r - hack * hs);
+        myLen = a.rS[myRow];
     }
-    const int groupLongest = waveMax(longest);
+    const int groupLongest = waveMax(myLen);
+    const T* __restrict__ vals = a.cM + slab;
+    const int* __restrict__ idxs = a.rP + slab;
 
-    T sum[OWN];
+    /* ---- team role ---- */
+    const int team = lane / KP;
+    const int t = lane % KP;
+    const int rhs0 = t * VEC;
+    const T* __restrict__ X = a.X + rhs0;
+
+    T sum[KP][VEC];
 #pragma unroll
-    for (int i = 0; i < OWN; ++i)
-        sum[i] = zeroOf<T>();
-
-    const T* __restrict__ vals = a.cM + slab + team;
-    const int* __restrict__ idxs = a.rP + slab + team;
-    const T* __restrict__ X = a.X + j;
+    for (int i = 0; i < KP; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            sum[i][e] = zeroOf<T>();
 
     for (int kBase = 0; kBase < groupLongest; kBase += UNROLL) {
+        T coefMine[UNROLL];
+        int colMine[UNROLL]; /* -1: no entry */
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = kBase + u;
-            const long long column = (long long)k * a.hackSize;
-            T coef[OWN];
-            int col[OWN];
-            bool use[OWN];
-#pragma unroll
-            for (int i = 0; i < OWN; ++i) {
-                use[i] = k < len[i];
-                coef[i] = use[i] ? vals[column + i * G] : zeroOf<T>();
-                col[i] = use[i] ? idxs[column + i * G] - a.baseIndex : 0;
-                use[i] = use[i] && col[i] >= 0 && rhsLive;
+            if (k < myLen) {
+                coefMine[u] = vals[(long long)k * a.hackSize];
+                colMine[u] = idxs[(long long)k * a.hackSize] - a.baseIndex;
+            } else {
+                coefMine[u] = zeroOf<T>();
+                colMine[u] = -1;
             }
-            T xv[OWN];
+        }
 #pragma unroll
-            for (int i = 0; i < OWN; ++i)
-                xv[i] = use[i] ? X[(long long)col[i] * a.ldX] : zeroOf<T>();
+        for (int u = 0; u < UNROLL; ++u) {
+            /* CHUNK rows of the team at a time: CHUNK gathers in flight per lane */
+            constexpr int CHUNK = KP < 4 ? KP : 4;
 #pragma unroll
-            for (int i = 0; i < OWN; ++i)
-                sum[i] = use[i] ? mulAdd(coef[i], xv[i], sum[i]) : sum[i];
+            for (int i0 = 0; i0 < KP; i0 += CHUNK) {
+                T coef[CHUNK];
+                int col[CHUNK];
+                Pack<T, VEC> xv[CHUNK];
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    const int src = team * KP + i0 + i;
+                    coef[i] = laneFrom(coefMine[u], src);
+                    col[i] = laneFrom(colMine[u], src);
+                }
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i) {
+                    if (col[i] >= 0 && rhs0 < a.count) {
+                        xv[i] = loadPack<false, T, VEC>(X + (long long)col[i] * a.ldX);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            xv[i].v[e] = zeroOf<T>();
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < CHUNK; ++i)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        sum[i0 + i][e] = pick(col[i] >= 0, mulAdd(coef[i], xv[i].v[e], sum[i0 + i][e]), sum[i0 + i][e]);
+                /* keep the scheduler from hoisting every chunk's shuffles and gathers to the top:
+                 * that costs registers (occupancy), not latency -- other wavefronts cover it */
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 
-    if (!rhsLive)
+    if (rhs0 >= a.count)
         return;
     const bool hasBeta = isNotZero(a.beta);
 #pragma unroll
-    for (int i = 0; i < OWN; ++i) {
-        const long long r = groupRow0 + team + (long long)i * G;
+    for (int i = 0; i < KP; ++i) {
+        const long long r = groupRow0 + team * KP + i;
         if (r < a.rows) {
             const long long outRow = a.rIdx ? a.rIdx[r] : r;
-            const long long at = outRow * a.ldYZ + j;
-            a.Z[at] = hasBeta ? epilogue<true>(a.alpha, sum[i], a.beta, a.Y[at])
-                              : epilogue<false>(a.alpha, sum[i], a.beta, zeroOf<T>());
+            const long long at = outRow * a.ldYZ + rhs0;
+            Pack<T, VEC> out;
+            if (hasBeta) {
+                const Pack<T, VEC> yv = loadPack<false, T, VEC>(a.Y + at);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    out.v[e] = epilogue<true>(a.alpha, sum[i][e], a.beta, yv.v[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    out.v[e] = epilogue<false>(a.alpha, sum[i][e], a.beta, zeroOf<T>());
+            }
+            storePack<T, VEC>(a.Z + at, out);
         }
+        __builtin_amdgcn_sched_barrier(0); /* one row's addresses and y values live at a time */
     }
+}
+
+template <typename T, int KP, int VEC, int UNROLL>
+static void launchSpmm(hipStream_t stream, const SpmmArgs<T>& a)
+{
+    const long long groups = ((long long)a.rows + kWave - 1) / kWave;
+    const unsigned blocks = (unsigned)((groups + kSpmmThreads / kWave - 1) / (kSpmmThreads / kWave));
+    hipLaunchKernelGGL((hellSpmmKernel<T, KP, VEC, UNROLL>), dim3(blocks), dim3(kSpmmThreads), 0, stream, a);
 }
 
 template <typename T>
@@ -135,15 +182,13 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
                      const int* hackOffsets, const int* rS, const int* rIdx, int rows, const T* X, T beta,
                      int baseIndex, int count, int ldX, int ldYZ)
 {
-    if (rows <= 0 || count <= 0)
+    if (rows <= 0 || count <= 0 || hackSize <= 0)
         return;
-    if (hackSize <= 0 || hackSize % kSpmmGroupRows != 0) {
-        fprintf(stderr, "spgpu?hellspmm: hackSize must be a positive multiple of 32 (got %d)\n", hackSize);
-        return;
-    }
     hipStream_t stream = handle->currentStream;
-    const long long groups = ((long long)rows + kSpmmGroupRows - 1) / kSpmmGroupRows;
-    const unsigned blocks = (unsigned)((groups + kSpmmThreads / kWave - 1) / (kSpmmThreads / kWave));
+    /* two right-hand sides per lane need 2*sizeof(T)-aligned rows of X, Y and Z */
+    const size_t pair = 2 * sizeof(T);
+    const bool pairsOk = ldX % 2 == 0 && ldYZ % 2 == 0 && (uintptr_t)X % pair == 0 && (uintptr_t)Z % pair == 0 &&
+                         (!Y || (uintptr_t)Y % pair == 0);
 
     for (int first = 0; first < count; first += 16) {
         SpmmArgs<T> a;
@@ -163,12 +208,20 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
         a.count = count - first < 16 ? count - first : 16;
         a.ldX = ldX;
         a.ldYZ = ldYZ;
-        if (a.count > 8)
-            hipLaunchKernelGGL((hellSpmmKernel<T, 16, 4>), dim3(blocks), dim3(kSpmmThreads), 0, stream, a);
-        else if (a.count > 4)
-            hipLaunchKernelGGL((hellSpmmKernel<T, 8, 4>), dim3(blocks), dim3(kSpmmThreads), 0, stream, a);
-        else
-            hipLaunchKernelGGL((hellSpmmKernel<T, 4, 2>), dim3(blocks), dim3(kSpmmThreads), 0, stream, a);
+        const bool pairs = pairsOk && a.count % 2 == 0;
+        if (a.count > 8) {
+            if (pairs)
+                launchSpmm<T, 8, 2, 2>(stream, a);
+            else
+                launchSpmm<T, 16, 1, 2>(stream, a);
+        } else if (a.count > 4) {
+            if (pairs)
+                launchSpmm<T, 4, 2, 4>(stream, a);
+            else
+                launchSpmm<T, 8, 1, 2>(stream, a);
+        } else {
+            launchSpmm<T, 4, 1, 4>(stream, a);
+        }
     }
     spgpuDebugCheck(handle, "hellspmm");
 }

@@ -39,6 +39,8 @@ __device__ inline double axpbyOne(double alpha, double x, double beta, double y)
 __device__ inline cfloat axpbyOne(cfloat alpha, cfloat x, cfloat beta, cfloat y) { return mulAdd(beta, y, mul(alpha, x)); }
 __device__ inline cdouble axpbyOne(cdouble alpha, cdouble x, cdouble beta, cdouble y) { return mulAdd(alpha, x, mul(beta, y)); }
 
+constexpr int kL1Unroll = 4; /* independent 16-byte accesses in flight per lane */
+
 template <typename T, int VEC, bool HAS_BETA>
 __global__ __launch_bounds__(kL1Threads) void axpbyKernel(T* z, int n, T beta, const T* y, T alpha, const T* x,
                                                          long long pitch)
@@ -50,21 +52,33 @@ __global__ __launch_bounds__(kL1Threads) void axpbyKernel(T* z, int n, T beta, c
         y += shift;
 
     const long long packs = n / VEC;
-    const long long stride = (long long)gridDim.x * kL1Threads;
-    for (long long p = (long long)blockIdx.x * kL1Threads + threadIdx.x; p < packs; p += stride) {
-        const Pack<T, VEC> xv = loadPack<false, T, VEC>(x + p * VEC);
-        Pack<T, VEC> out;
-        if constexpr (HAS_BETA) {
-            const Pack<T, VEC> yv = loadPack<false, T, VEC>(y + p * VEC);
+    constexpr long long TILE = (long long)kL1Threads * kL1Unroll;
+    for (long long base = (long long)blockIdx.x * TILE; base < packs; base += (long long)gridDim.x * TILE) {
+        Pack<T, VEC> xv[kL1Unroll], yv[kL1Unroll];
 #pragma unroll
-            for (int t = 0; t < VEC; ++t)
-                out.v[t] = axpbyOne(alpha, xv.v[t], beta, yv.v[t]);
-        } else {
-#pragma unroll
-            for (int t = 0; t < VEC; ++t)
-                out.v[t] = mul(alpha, xv.v[t]);
+        for (int u = 0; u < kL1Unroll; ++u) {
+            const long long p = base + u * kL1Threads + threadIdx.x;
+            if (p < packs) {
+                xv[u] = loadPack<false, T, VEC>(x + p * VEC);
+                if constexpr (HAS_BETA)
+                    yv[u] = loadPack<false, T, VEC>(y + p * VEC);
+            }
         }
-        storePack<T, VEC>(z + p * VEC, out);
+#pragma unroll
+        for (int u = 0; u < kL1Unroll; ++u) {
+            const long long p = base + u * kL1Threads + threadIdx.x;
+            if (p < packs) {
+                Pack<T, VEC> out;
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) {
+                    if constexpr (HAS_BETA)
+                        out.v[t] = axpbyOne(alpha, xv[u].v[t], beta, yv[u].v[t]);
+                    else
+                        out.v[t] = mul(alpha, xv[u].v[t]);
+                }
+                storePack<T, VEC>(z + p * VEC, out);
+            }
+        }
     }
     /* tail (n % VEC elements) */
     const long long tail = packs * VEC + (long long)blockIdx.x * kL1Threads + threadIdx.x;
@@ -93,7 +107,7 @@ static void axpbyLaunch(spgpuHandle_t handle, ApiT* zApi, int n, ApiT betaApi, A
     const bool wide = WIDE > 1 && ((uintptr_t)z % 16 == 0) && ((uintptr_t)x % 16 == 0) &&
                       (!hasBeta || (uintptr_t)y % 16 == 0) && (count == 1 || pitch % WIDE == 0);
     const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
-    long long blocks = (work + kL1Threads - 1) / kL1Threads;
+    long long blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
     const long long cap = kL1MaxBlocks / (count < kL1MaxBlocks ? count : kL1MaxBlocks);
     if (blocks > (cap > 1 ? cap : 1))
         blocks = cap > 1 ? cap : 1;
@@ -158,18 +172,31 @@ __global__ __launch_bounds__(kL1Threads) void reduceKernel(typename std::conditi
 
     Acc acc = zeroOf<Acc>();
     const long long packs = n / VEC;
-    const long long stride = (long long)gridDim.x * kL1Threads;
-    for (long long p = (long long)blockIdx.x * kL1Threads + threadIdx.x; p < packs; p += stride) {
-        const Pack<T, VEC> av = loadPack<false, T, VEC>(a + p * VEC);
-        if constexpr (NRM2) {
+    constexpr long long TILE = (long long)kL1Threads * kL1Unroll;
+    for (long long base = (long long)blockIdx.x * TILE; base < packs; base += (long long)gridDim.x * TILE) {
+        Pack<T, VEC> av[kL1Unroll], bv[kL1Unroll];
+        bool live[kL1Unroll];
 #pragma unroll
-            for (int t = 0; t < VEC; ++t)
-                acc = absSqAdd(av.v[t], acc);
-        } else {
-            const Pack<T, VEC> bv = loadPack<false, T, VEC>(b + p * VEC);
+        for (int u = 0; u < kL1Unroll; ++u) {
+            const long long p = base + u * kL1Threads + threadIdx.x;
+            live[u] = p < packs;
+            if (live[u]) {
+                av[u] = loadPack<false, T, VEC>(a + p * VEC);
+                if constexpr (!NRM2)
+                    bv[u] = loadPack<false, T, VEC>(b + p * VEC);
+            }
+        }
 #pragma unroll
-            for (int t = 0; t < VEC; ++t)
-                acc = mulAdd(av.v[t], bv.v[t], acc);
+        for (int u = 0; u < kL1Unroll; ++u) {
+            if (live[u]) {
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) {
+                    if constexpr (NRM2)
+                        acc = absSqAdd(av[u].v[t], acc);
+                    else
+                        acc = mulAdd(av[u].v[t], bv[u].v[t], acc);
+                }
+            }
         }
     }
     const long long tail = packs * VEC + (long long)blockIdx.x * kL1Threads + threadIdx.x;
@@ -210,7 +237,7 @@ static void reduceVectors(spgpuHandle_t handle, Acc* out, int n, const T* a, con
         const bool wide = WIDE > 1 && ((uintptr_t)a0 % 16 == 0) && (NRM2 || (uintptr_t)b0 % 16 == 0) &&
                           (vectors == 1 || pitch % WIDE == 0);
         const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
-        long long blocks = (work + kL1Threads - 1) / kL1Threads;
+        long long blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
         const long long cap = SPGPU_REDUCE_MAX_BLOCKS / vectors;
         if (blocks > cap)
             blocks = cap;

@@ -61,6 +61,15 @@ template <typename R> __device__ inline Cx<R> mul(Cx<R> a, Cx<R> b)
 }
 template <typename R> __device__ __host__ inline Cx<R> add(Cx<R> a, Cx<R> b) { return Cx<R>{a.x + b.x, a.y + b.y}; }
 
+/* ---- branch-free select.  Written per component for complex values: a ?: on the
+ * whole struct makes hipcc keep the running sums in scratch memory. */
+__device__ inline float pick(bool c, float a, float b) { return c ? a : b; }
+__device__ inline double pick(bool c, double a, double b) { return c ? a : b; }
+template <typename R> __device__ inline Cx<R> pick(bool c, Cx<R> a, Cx<R> b)
+{
+    return Cx<R>{c ? a.x : b.x, c ? a.y : b.y};
+}
+
 /* ---- SpMV epilogue (reference: hell_spmv_base_template.cuh:219-222) ------ */
 template <bool HAS_BETA, typename T> __device__ inline T epilogue(T alpha, T rowSum, T beta, T yVal)
 {

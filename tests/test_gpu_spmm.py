@@ -88,3 +88,32 @@ def test_multivector_layout_converters(gpu, letter):
         assert np.array_equal(got[:, j], src[j * pitch:j * pitch + n])
         assert np.array_equal(back.cpu().numpy()[j * pitch:j * pitch + n], src[j * pitch:j * pitch + n])
     assert not np.any(got[:, count:])
+
+
+@pytest.mark.parametrize("pattern", ["banded", "random"])
+def test_own_rest_column_split_reproduces_the_block(gpu, pattern):
+    """bench.py's overlap path: a row block cut by column ownership (own + rest) gives the block's product."""
+    import torch
+    from spgpu_amd import capi, synth
+    rows, n_total, L, k, first = 3200, 12800, 32, 16, 6400
+    block = synth.hell_uniform_on_device(rows, L, pattern, "D", 32, seed=5, n_cols=n_total, row_offset=first)
+    own, rest = synth.split_uniform_hell_by_columns(block, first, rows)
+    assert own["nnz"] + rest["nnz"] == block["nnz"]
+    X = synth.device_vector(n_total * k, "D", 6).view(n_total, k)
+    torch.cuda.synchronize()
+
+    def product(part, Z, Y, Xt, beta):
+        capi.hellspmm["D"](gpu, _p(Z), _p(Y), 1.0, _p(part["cM"]), _p(part["rP"]), 32, _p(part["hack_offsets"]),
+                           _p(part["rS"]), None, L, rows, _p(Xt), beta, 0, k, k, k)
+
+    z_whole = torch.empty(rows, k, dtype=torch.float64, device="cuda:0")
+    z_split = torch.empty_like(z_whole)
+    product(block, z_whole, None, X, 0.0)
+    product(own, z_split, None, X[first:first + rows], 0.0)     # columns rebased to the owned X block
+    product(rest, z_split, z_split, X, 1.0)
+    torch.cuda.synchronize()
+    a, b = z_whole.cpu().numpy(), z_split.cpu().numpy()
+    assert np.max(np.abs(a - b) / (np.abs(a) + 1.0)) <= 1e-13
+    # and the whole block against the oracle, bit for bit
+    sub = synth.hell_rows_to_host(block, 0, rows)
+    assert a.tobytes() == O.hell_spmm(sub, X.cpu().numpy(), None, 1.0, 0.0).tobytes()

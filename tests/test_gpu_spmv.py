@@ -1,9 +1,9 @@
 """GPU: parity of the HIP kernels, called through the C ABI, against the oracle and the
 golden fixtures.  Tolerance (north_star): 1e-6 (fp64) / 1e-4 (fp32) of the row magnitude;
 in addition the kernels are compared BIT FOR BIT with the oracle run in the kernel's own
-summation order (S: 8 phases, D/C: 4, Z: 2 for the wide slab kernel; 2 / 1 for the
-narrow variants), which is stricter than the contract and catches indexing slips that a
-tolerance would hide."""
+summation order (default dispatch: D/C ascending k like the reference's one-thread-per-row
+kernel, S 8 phases, Z 2 phases like the reference's two-threads-per-row kernel), which is
+stricter than the contract and catches indexing slips that a tolerance would hide."""
 import ctypes as C
 import glob
 import os
@@ -16,8 +16,10 @@ import oracle_api as O
 pytestmark = pytest.mark.gpu
 
 TOL = {"S": 1e-4, "C": 1e-4, "D": 1e-6, "Z": 1e-6}
-WIDE_PHASES = {"S": 8, "D": 4, "C": 4, "Z": 2}   # default dispatch of ellpack_spmv.hip
-VARIANT_PHASES = {1: WIDE_PHASES, 2: dict.fromkeys("SDCZ", 1), 3: dict.fromkeys("SDCZ", 2), 4: dict.fromkeys("SDCZ", 1)}
+WIDE_PHASES = {"S": 8, "D": 1, "C": 1, "Z": 2}   # default dispatch of ellpack_spmv.hip (launchSlabFamily)
+_ONE, _TWO = dict.fromkeys("SDCZ", 1), dict.fromkeys("SDCZ", 2)
+_PHX2 = {"S": 8, "D": 4, "C": 4, "Z": 2}       # wide kernel with 2*RPL phases (Z has RPL 1: narrow, 2 phases)
+VARIANT_PHASES = {1: _PHX2, 2: {**_ONE, "Z": 2}, 3: _TWO, 4: _ONE, 6: _PHX2, 12: {**_ONE, "Z": 2}, 13: _TWO}
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
 
@@ -90,16 +92,14 @@ def test_fixture_parity_all_formats(gpu, name):
         assert z.tobytes() == O.hdia_spmv(hdia, g["x"], y, alpha, beta).tobytes()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 12, 13])
 @pytest.mark.parametrize("name", ["powerlaw_s_b1_h64", "powerlaw_d_b0_h32", "powerlaw_c_b0_h32", "powerlaw_z_b1_h64"])
 def test_every_kernel_variant_bit_exact(gpu, name, variant, monkeypatch):
     from spgpu_amd import formats
     monkeypatch.setenv("SPGPU_SPMV_VARIANT", str(variant))
     g = _load(name)
     letter, ell, hell, _ = _mats(g)
-    ph = VARIANT_PHASES[variant][letter]
-    if letter == "Z" and variant <= 2:
-        ph = {1: 2, 2: 1}[variant]   # 16-byte elements: RPL is 1 already
+    ph = VARIANT_PHASES[variant][letter]   # Z (16-byte elements) has no wide form: wide requests run narrow 2x4 pipe
     for beta in (0.0, g["beta"][()] if g["beta"][()] != 0 else 0.5):
         y = g["y"] if beta != 0 else None
         z = _run(gpu, formats.DeviceHell(hell), g["x"], y, g["alpha"][()], beta)

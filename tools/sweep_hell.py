@@ -28,9 +28,10 @@ for pattern in patterns:
     one, zero = capi.scalar(letter, 1.0), capi.scalar(letter, 0.0)
     call = lambda: capi.hellspmv[letter](handle, p(z), p(y), one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]),
                                          p(h["rS"]), None, L, rows, p(x), zero, 0)
-    configs = [(v, nt) for v in (1, 2, 3, 4) for nt in (1, 0)]
+    variants = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "1,2,3,4").split(",")]
+    configs = [(v, nt) for v in variants for nt in ([1, 0] if os.environ.get("SWEEP_NT", "both") == "both" else [1])]
     best = {}
-    for rnd in range(3):
+    for rnd in range(int(os.environ.get("SWEEP_ROUNDS", 3))):
         for v, nt in configs:
             os.environ["SPGPU_SPMV_VARIANT"], os.environ["SPGPU_NT_LOADS"] = str(v), str(nt)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
