@@ -232,3 +232,95 @@ def split_uniform_hell_by_columns(h, col_first, col_count):
                     rS=lengths.reshape(-1).to(torch.int32).contiguous(), base=0, slots=total)
 
     return compact(own_mask, col_first), compact(~own_mask, 0)
+
+
+def hdia_laplacian7_on_device(m, letter="D", hack_size=32, device="cuda:0"):
+    """HDIA arrays of the 7-point Laplacian on an m^3 grid (BASELINE config 4: m = 512), built in HBM.
+    Equals what cooToHdia (hdia.cpp:230-349) produces from laplacian_3d_7pt(m) -- checked bit for bit on
+    small m in tests/test_gpu_fullsize.py.  Needs m % hack_size == 0 so that a hack lies inside one grid
+    line: then its diagonals are -m^2 (gz>0), -m (gy>0), -1, 0, +1, +m (gy<m-1), +m^2 (gz<m-1) and only the
+    +-1 diagonals hold explicit zeros (at gx = 0 resp. gx = m-1)."""
+    import torch
+    assert m % hack_size == 0
+    hs, n = hack_size, m * m * m
+    hacks = n // hs
+    tdt = {"S": torch.float32, "D": torch.float64}[letter]
+    h = torch.arange(hacks, device=device, dtype=torch.int64)
+    row0 = h * hs
+    gx0, gy, gz = row0 % m, (row0 // m) % m, row0 // (m * m)
+    cand = torch.tensor([-m * m, -m, -1, 0, 1, m, m * m], device=device, dtype=torch.int64)
+    true = torch.ones(hacks, dtype=torch.bool, device=device)
+    present = torch.stack([gz > 0, gy > 0, true, true, true, gy < m - 1, gz < m - 1], dim=1)   # [hacks, 7]
+    counts = present.sum(dim=1)
+    hack_offsets = torch.zeros(hacks + 1, dtype=torch.int64, device=device)
+    hack_offsets[1:] = torch.cumsum(counts, 0)
+    offsets = cand[None, :].expand(hacks, 7)[present]                                         # ascending per hack
+    owner = torch.arange(hacks, device=device, dtype=torch.int64)[:, None].expand(hacks, 7)[present]
+    H = int(offsets.numel())
+    dM = torch.where(offsets == 0, 6.0, -1.0).to(tdt)[:, None].expand(H, hs).contiguous()
+    # explicit zeros: left neighbour missing at gx == 0 (lane 0 of hacks starting a grid line),
+    # right neighbour missing at gx == m-1 (last lane of hacks ending a grid line)
+    left = (offsets == -1) & (gx0[owner] == 0)
+    right = (offsets == 1) & (gx0[owner] + hs == m)
+    dM[left, 0] = 0
+    dM[right, hs - 1] = 0
+    nnz = 7 * n - 6 * m * m
+    return dict(letter=letter, rows=n, cols=n, hack_size=hs, height=H, nnz=nnz, dM=dM.reshape(-1),
+                offsets=offsets.to(torch.int32), hack_offsets=hack_offsets.to(torch.int32))
+
+
+def hell_ragged_on_device(lengths, n_cols, letter="S", hack_size=32, seed=5, device="cuda:0"):
+    """HELL arrays for given row lengths (BASELINE config 3: power-law lengths), built in HBM.
+    Every slot, padding included, gets a random valid column and coefficient: padding slots
+    (k >= rS[row]) are never used by the kernels, exactly as with the reference's malloc'd HELL
+    arrays (hellPerf.cpp:258-259)."""
+    import torch
+    hs = hack_size
+    L = torch.as_tensor(lengths, dtype=torch.int64, device=device)
+    rows = int(L.numel())
+    hacks = (rows + hs - 1) // hs
+    padded = torch.zeros(hacks * hs, dtype=torch.int64, device=device)
+    padded[:rows] = L
+    depth = padded.view(hacks, hs).max(dim=1).values
+    hack_offsets = torch.cumsum(depth * hs, 0) - depth * hs
+    slots = int((depth * hs).sum().item())
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    rdt = {"S": torch.float32, "D": torch.float64}[letter]
+    rP = torch.randint(0, n_cols, (max(slots, 1),), device=device, generator=gen, dtype=torch.int32)
+    cM = torch.rand(max(slots, 1), device=device, generator=gen, dtype=rdt)
+    return dict(letter=letter, rows=rows, cols=n_cols, hack_size=hs, nnz=int(L.sum().item()), cM=cM, rP=rP,
+                hack_offsets=hack_offsets.to(torch.int32), rS=L.to(torch.int32), base=0, slots=slots,
+                depth=depth)
+
+
+def ell_ragged_on_device(lengths, n_cols, letter="S", seed=6, device="cuda:0"):
+    """ELL arrays (pitch = rows rounded up to 32, max row length columns) for given row lengths, built in
+    HBM; every slot random like hell_ragged_on_device.  Footprint = pitch * max_len * (sizeof(T)+4)."""
+    import torch
+    L = torch.as_tensor(lengths, dtype=torch.int32, device=device)
+    rows = int(L.numel())
+    pitch = (rows + 31) // 32 * 32
+    max_len = int(L.max().item())
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    rdt = {"S": torch.float32, "D": torch.float64}[letter]
+    rP = torch.randint(0, n_cols, (pitch * max_len,), device=device, generator=gen, dtype=torch.int32)
+    cM = torch.rand(pitch * max_len, device=device, generator=gen, dtype=rdt)
+    return dict(letter=letter, rows=rows, cols=n_cols, pitch=pitch, max_row=max_len, nnz=int(L.sum().item()),
+                cM=cM, rP=rP, rS=L, base=0)
+
+
+def ragged_rows_to_host(h, first_row, n_rows):
+    """Rows [first_row, first_row+n_rows) (hack-aligned) of a device HELL dict from hell_ragged_on_device
+    as a host HELL dict with rebased hackOffsets."""
+    import numpy as np
+    hs = h["hack_size"]
+    assert first_row % hs == 0 and n_rows % hs == 0
+    h0, h1 = first_row // hs, (first_row + n_rows) // hs
+    ho = h["hack_offsets"].cpu().numpy().astype(np.int64)
+    s0 = int(ho[h0])
+    s1 = int(ho[h1]) if h1 < ho.size else int(h["slots"])
+    return dict(letter=h["letter"], rows=n_rows, values=h["cM"][s0:s1].cpu().numpy(), indices=h["rP"][s0:s1].cpu().numpy(),
+                hack_offsets=(ho[h0:h1] - s0).astype(np.int32), hack_size=hs,
+                row_lengths=h["rS"][first_row:first_row + n_rows].cpu().numpy(), base=0)
