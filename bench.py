@@ -55,6 +55,24 @@ def hell_algorithmic_bytes(nnz, rows, cols, hacks, elem=8, beta_nonzero=False, r
     return matrix + rhs * vectors
 
 
+def committed_traffic(rows, nnz_per_row, pattern):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
+    and --pmc WRITE_SIZE, separate runs, gfx950 x2 correction on FETCH_SIZE), if they were taken on
+    this workload; None otherwise.  bench.py itself cannot collect counters."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_spmv_pmc.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        w = d.get("workload", dict(rows=10_000_000, nnz_per_row=32, pattern="banded"))
+        if (w.get("rows"), w.get("nnz_per_row"), w.get("pattern")) == (rows, nnz_per_row, pattern):
+            best = int(d["hbm_traffic_bytes_per_launch"])
+    return best
+
+
 def time_launches(stream, fn, steps):
     """HIP events on the stream the kernels are launched on; returns seconds for `steps` launches."""
     import torch
@@ -86,26 +104,57 @@ def spot_check_hell(h, x, y, z, alpha, beta, phases=1, rows_per_probe=2048):
     return "bit-exact vs oracle on 3 x %d rows" % rows_per_probe
 
 
+def usable_cores():
+    """Host cores this process may really use: cgroup CPU quota if there is one, else the affinity
+    mask; the GPU boxes expose 128 hardware threads but give a 1-GPU job a 16-CPU share."""
+    n = len(os.sched_getaffinity(0))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            with open(path) as f:
+                quota, period = parse(f.read())
+            if period is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = f.read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    if "OMP_NUM_THREADS" in os.environ:
+        n = int(os.environ["OMP_NUM_THREADS"])
+    elif n > 32:
+        n = 16
+    return n
+
+
 def cpu_baseline(h, x, seconds):
-    """The oracle's HELL SpMV (OpenMP over rows) on the first rows of the same matrix."""
+    """cpu_baseline leg: the oracle's HELL SpMV (orc_dhellspmv, OpenMP over rows; a PORT -- the
+    reference has no CPU SpMV) on the first rows of the same matrix, called straight through ctypes
+    on pre-converted arrays so that only the C loop is timed."""
     import numpy as np
     import oracle_api as O
     from spgpu_amd import synth
     sample_rows = min(h["rows"], 2_000_000) // h["hack_size"] * h["hack_size"]
     sub = synth.hell_rows_to_host(h, 0, sample_rows)
-    xs = x.cpu().numpy()
+    xs = np.ascontiguousarray(x.cpu().numpy())
+    zs = np.zeros(sample_rows)
     nnz = int(sub["row_lengths"].sum(dtype=np.int64))
-    O.hell_spmv(sub, xs, None, 1.0, 0.0)  # warm the pages
+    cores = usable_cores()
+    O.orc.orc_set_threads(cores)
+    ptr = lambda a: C.c_void_p(a.ctypes.data)
+    call = lambda: O.orc.orc_dhellspmv(ptr(zs), None, C.c_double(1.0), ptr(sub["values"]), ptr(sub["indices"]),
+                                       sub["hack_size"], ptr(sub["hack_offsets"]), ptr(sub["row_lengths"]), None,
+                                       sample_rows, ptr(xs), C.c_double(0.0), 0, 1)
+    call()  # warm the pages
     t0, passes = time.perf_counter(), 0
     while True:
-        O.hell_spmv(sub, xs, None, 1.0, 0.0)
+        call()
         passes += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or passes >= 200:
+        if dt >= seconds or passes >= 1000:
             break
-    cores = int(O.orc.orc_threads())
     return dict(value=round(2.0 * nnz * passes / dt * 1e-9, 3), unit="GFLOP/s", cores=cores, kind="port",
-                sample=f"oracle orc_dhellspmv (OpenMP, {cores} threads) on the first {sample_rows} rows "
+                sample=f"oracle orc_dhellspmv (C, OpenMP, {cores} threads) on the first {sample_rows} rows "
                        f"({nnz} nnz) of the same matrix, {passes} passes in {dt:.1f} s")
 
 
@@ -170,7 +219,8 @@ def run_spmv(args, rank, world):
                     rows=h["rows"], nnz=h["nnz"], hack_size=32, pattern=args.pattern,
                     parallelism="single GPU" if world == 1 else f"{world} independent replicas"),
         roofline=dict(bound="hbm", achieved=round(alg / per_launch * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                      frac=round(alg / per_launch * 1e-9 / HBM_PEAK_GBS, 4), traffic=None,
+                      frac=round(alg / per_launch * 1e-9 / HBM_PEAK_GBS, 4),
+                      traffic=committed_traffic(h["rows"], args.nnz_per_row, args.pattern),
                       kernel="slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, pipelined>", algorithmic_bytes_per_launch=alg,
                       kernel_ms=round(per_launch * 1e3, 5)),
     )
