@@ -45,14 +45,19 @@ template <typename T> struct HdiaArgs {
     T alpha, beta;
     int rows, cols, hackSize;
     int wideIO;
+    int xcdOrder; /* 0: hardware order; 1: XCD-contiguous eighths; n > 1: runs of n blocks per XCD */
 };
 
-constexpr int kHdiaThreads = 256;
 
-template <typename T, int RPL, bool NT, int UNROLL>
+/* XWIDE: read the RPL consecutive x values of a strip with one (element-aligned) wide load when the
+ * whole strip is in range. */
+template <typename T, int RPL, bool NT, int UNROLL, bool XWIDE, int kHdiaThreads>
 __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T> a)
 {
-    const long long strip = (long long)blockIdx.x * kHdiaThreads + threadIdx.x;
+    const unsigned block = a.xcdOrder == 0 ? blockIdx.x
+                         : a.xcdOrder == 1 ? xcdContiguous(blockIdx.x, gridDim.x)
+                                           : xcdRuns(blockIdx.x, gridDim.x, (unsigned)a.xcdOrder);
+    const long long strip = (long long)block * kHdiaThreads + threadIdx.x;
     const long long waveRow0 = (strip - (threadIdx.x & (kWave - 1))) * RPL;
     if (waveRow0 >= a.rows)
         return; /* whole wavefront leaves together */
@@ -70,53 +75,58 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
         slab = (long long)firstDiag * hs + (r0 - hack * hs);
     }
     const int waveDiags = waveMax(diags); /* wave-uniform trip count */
+    const bool stripInside = row0 + RPL <= a.rows;
 
-    bool rowLive[RPL];
     T sum[RPL];
 #pragma unroll
-    for (int t = 0; t < RPL; ++t) {
-        rowLive[t] = row0 + t < a.rows;
+    for (int t = 0; t < RPL; ++t)
         sum[t] = zeroOf<T>();
-    }
 
     const T* __restrict__ vals = a.dM + slab;
     const int* __restrict__ offs = a.offsets + firstDiag;
     const T* __restrict__ x = a.x;
 
     for (int dBase = 0; dBase < waveDiags; dBase += UNROLL) {
+        /* coefficient loads do not depend on the offsets: issue them first */
+        Pack<T, RPL> v[UNROLL];
         int off[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-            off[u] = dBase + u < diags ? offs[dBase + u] : 0;
-
-        Pack<T, RPL> v[UNROLL];
-        T xv[UNROLL][RPL];
-        bool use[UNROLL][RPL];
-#pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            const long long col0 = row0 + off[u];
-            bool any = false;
-#pragma unroll
-            for (int t = 0; t < RPL; ++t) {
-                const long long col = col0 + t;
-                use[u][t] = dBase + u < diags && rowLive[t] && col >= 0 && col < a.cols;
-                any = any || use[u][t];
-                xv[u][t] = x[use[u][t] ? col : 0];
-            }
-            if (any) {
+            if (dBase + u < diags) {
                 v[u] = loadPack<NT, T, RPL>(vals + (long long)(dBase + u) * a.hackSize);
+                off[u] = offs[dBase + u];
             } else {
 #pragma unroll
                 for (int t = 0; t < RPL; ++t)
                     v[u].v[t] = zeroOf<T>();
+                off[u] = 0;
+            }
+        }
+        Pack<T, RPL> xv[UNROLL];
+        bool use[UNROLL][RPL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long long col0 = row0 + off[u];
+            const bool dLive = dBase + u < diags;
+            if (XWIDE && RPL > 1 && dLive && stripInside && col0 >= 0 && col0 + RPL <= a.cols) {
+                xv[u] = loadPackElemAligned<T, RPL>(x + col0);
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    use[u][t] = true;
+            } else {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    const long long col = col0 + t;
+                    use[u][t] = dLive && row0 + t < a.rows && col >= 0 && col < a.cols;
+                    xv[u].v[t] = x[use[u][t] ? col : 0];
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
-            for (int t = 0; t < RPL; ++t) {
-                sum[t] = pick(use[u][t], mulAdd(v[u].v[t], xv[u][t], sum[t]), sum[t]);
-            }
+            for (int t = 0; t < RPL; ++t)
+                sum[t] = pick(use[u][t], mulAdd(v[u].v[t], xv[u].v[t], sum[t]), sum[t]);
         }
     }
 
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
         return;
 
     const bool hasBeta = isNotZero(a.beta);
-    if (a.wideIO && row0 + RPL <= a.rows) {
+    if (a.wideIO && stripInside) {
         Pack<T, RPL> out;
         if (hasBeta) {
             const Pack<T, RPL> yv = loadPack<false, T, RPL>(a.y + row0);
@@ -140,22 +150,36 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
     } else {
 #pragma unroll
         for (int t = 0; t < RPL; ++t) {
-            if (rowLive[t])
+            if (row0 + t < a.rows)
                 a.z[row0 + t] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[row0 + t])
                                         : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
         }
     }
 }
 
-template <typename T, int RPL, int UNROLL>
-static void launchHdia(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
+template <typename T, int RPL, int UNROLL, bool XWIDE, int kHdiaThreads>
+static void launchHdiaSized(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
 {
     const long long strips = ((long long)a.rows + RPL - 1) / RPL;
     const unsigned blocks = (unsigned)((strips + kHdiaThreads - 1) / kHdiaThreads);
     if (nt)
-        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, true, UNROLL>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
+        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, true, UNROLL, XWIDE, kHdiaThreads>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, false, UNROLL>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
+        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, false, UNROLL, XWIDE, kHdiaThreads>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
+}
+
+template <typename T, int RPL, int UNROLL, bool XWIDE>
+static void launchHdia(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
+{
+    /* SPGPU_HDIA_BLOCK (experiments): workgroup size 256 (default) / 512 / 1024 */
+    const char* bs = getenv("SPGPU_HDIA_BLOCK");
+    const int block = bs && *bs ? atoi(bs) : 256;
+    if (block == 1024)
+        launchHdiaSized<T, RPL, UNROLL, XWIDE, 1024>(stream, a, nt);
+    else if (block == 512)
+        launchHdiaSized<T, RPL, UNROLL, XWIDE, 512>(stream, a, nt);
+    else
+        launchHdiaSized<T, RPL, UNROLL, XWIDE, 256>(stream, a, nt);
 }
 
 template <typename T, typename ApiT>
@@ -178,6 +202,8 @@ static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     a.cols = cols;
     a.hackSize = hackSize;
 
+    const char* xo = getenv("SPGPU_XCD_ORDER");
+    a.xcdOrder = xo && *xo ? atoi(xo) : 0;
     constexpr int WIDE = 16 / (int)sizeof(T);
     const char* env = getenv("SPGPU_NT_LOADS");
     const bool nt = !(env && *env == '0');
@@ -188,13 +214,23 @@ static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     if constexpr (WIDE > 1) {
         if (wideOk) {
             a.wideIO = ((uintptr_t)z % 16 == 0) && ((uintptr_t)y % 16 == 0);
-            launchHdia<T, WIDE, 4>(stream, a, nt);
+            /* SPGPU_HDIA_VARIANT (experiments): 1 = 4 diagonals/stage, 2 = 8 (default), 3 = 8 + paired x loads.
+             * Measured on 512^3 (tools/ab_hdia.py): all within 1 %; XCD-contiguous block orders and
+             * workgroups of 512/1024 lanes are 2-13 % slower than the hardware order with 256. */
+            const char* hv = getenv("SPGPU_HDIA_VARIANT");
+            const int variant = hv && *hv ? atoi(hv) : 0;
+            if (variant == 1)
+                launchHdia<T, WIDE, 4, false>(stream, a, nt);
+            else if (variant == 3)
+                launchHdia<T, WIDE, 8, true>(stream, a, nt);
+            else
+                launchHdia<T, WIDE, 8, false>(stream, a, nt);
             spgpuDebugCheck(handle, "hdiaspmv");
             return;
         }
     }
     a.wideIO = 1;
-    launchHdia<T, 1, 4>(stream, a, nt);
+    launchHdia<T, 1, 8, false>(stream, a, nt);
     spgpuDebugCheck(handle, "hdiaspmv");
 }
 

@@ -102,12 +102,49 @@ template <bool NT, typename E, int N> __device__ inline Pack<E, N> loadPack(cons
     return out;
 }
 
+/* The same move from an address that is only aligned to sizeof(E): gfx950 runs global memory in
+ * unaligned-access mode, so this is still one wide load when the compiler is told the truth
+ * about the alignment. */
+template <typename E, int N> __device__ inline Pack<E, N> loadPackElemAligned(const E* p)
+{
+    struct __attribute__((packed, aligned(alignof(E)))) Loose { E v[N]; };
+    const Loose raw = *reinterpret_cast<const Loose*>(p);
+    Pack<E, N> out;
+    __builtin_memcpy(&out, &raw, sizeof(out));
+    return out;
+}
+
 template <typename E, int N> __device__ inline void storePack(E* p, const Pack<E, N>& value)
 {
     using Raw = typename RawBits<sizeof(E) * N>::type;
     Raw raw;
     __builtin_memcpy(&raw, &value, sizeof(raw));
     *reinterpret_cast<Raw*>(p) = raw;
+}
+
+/* ---- XCD-aware workgroup order ------------------------------------------------
+ * MI355X deals consecutive workgroup ids round-robin over its 8 XCDs (observed dispatch
+ * behaviour, MI355X_MICROARCH.md; used for speed only, never for correctness), and every
+ * XCD has a private 4 MiB L2.  This bijection of [0, groups) hands XCD j the j-th
+ * CONTIGUOUS eighth of the work, so that neighbouring row blocks -- which read
+ * neighbouring pieces of x -- share one L2 instead of each pulling the same lines
+ * over the fabric. */
+constexpr unsigned kXcds = 8;
+__device__ inline unsigned xcdContiguous(unsigned id, unsigned groups)
+{
+    const unsigned q = groups / kXcds, r = groups % kXcds;
+    const unsigned xcd = id % kXcds, slot = id / kXcds;
+    return xcd * q + (xcd < r ? xcd : r) + slot;
+}
+/* Finer grain: runs of `run` consecutive work items per XCD (run = 1 is the hardware's own
+ * order).  Bijective on the first floor(groups / (8*run)) * 8*run ids, identity on the tail. */
+__device__ inline unsigned xcdRuns(unsigned id, unsigned groups, unsigned run)
+{
+    const unsigned span = kXcds * run;
+    if (id >= groups / span * span)
+        return id;
+    const unsigned xcd = id % kXcds, slot = id / kXcds;
+    return (slot / run * kXcds + xcd) * run + slot % run;
 }
 
 /* ---- wavefront shuffles (lower to DPP / ds_bpermute, no LDS allocation) -- */
