@@ -12,7 +12,7 @@
  *    PINNED bit-exact against the reference's own converters, compiled from
  *    /root/reference into oracle/_ref (see oracle/Makefile) and compared on
  *    randomised inputs (tests/test_oracle_vs_reference.py), against fixtures that
- *    build produced (tests/golden/*.npz, oracle/make_golden.py) and against the
+ *    build produced (tests/golden/ (npz files), oracle/make_golden.py) and against the
  *    structural known answers of SURVEY.md section 8(a) (pitch, heights, hack
  *    offsets, diagonal sets; tests/test_oracle_golden.py).
  *  - SpMV / axpby / dot values: the reference has NO CPU implementation of
@@ -23,7 +23,7 @@
  *    beta = -3  =>  z = 4x - 3y), by the cross-format equalities its perf
  *    tests rely on (ELL == HELL == HDIA results), and by an independent
  *    extended-precision product computed from the COO triplets
- *    (oracle/make_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py).
+ *    (oracle/make_golden.py -> tests/golden/ (npz files), tests/test_oracle_golden.py).
  *
  * Every routine exists in four flavours generated from one macro body:
  * s (float), d (double), c (float complex), z (double complex).
@@ -498,6 +498,132 @@ void orc_zaxpby(orc_cdouble* z, int n, orc_cdouble beta, const orc_cdouble* y, o
 {
     for (int i = 0; i < n; ++i)
         z[i] = z_nz(beta) ? z_fma(alpha, x[i], z_mul(beta, y[i])) : z_mul(alpha, x[i]);
+}
+
+/* ======================================================================== */
+/* Rest of Level-1: scal_base.cuh:34-45, abs_base.cuh:43-70,    */
+/* axy_base.cuh:37-47,95-176, gath_base.cuh:32-45, scat_base.cuh:32-48,       */
+/* setscal_base.cuh:32-82; asum/amax follow the DOCUMENTED semantics          */
+/* (vector.h:319-339), not the defective final reduction of asum_base.cuh.    */
+/* ======================================================================== */
+
+/* cuCabs / cuCabsf (CUDA cuComplex.h): v*sqrt(1 + (w/v)^2), v = max(|re|,|im|), w = min. */
+static inline float s_mag(float v) { return fabsf(v); }
+static inline double d_mag(double v) { return fabs(v); }
+static inline float c_mag(orc_cfloat z)
+{
+    const float a = fabsf(z.x), b = fabsf(z.y), v = a > b ? a : b, w = a > b ? b : a;
+    float t = w / v;
+    t = fmaf(t, t, 1.0f);
+    t = v * sqrtf(t);
+    return (v == 0.0f || v > 3.402823466e38f || w > 3.402823466e38f) ? v + w : t;
+}
+static inline double z_mag(orc_cdouble z)
+{
+    const double a = fabs(z.x), b = fabs(z.y), v = a > b ? a : b, w = a > b ? b : a;
+    double t = w / v;
+    t = fma(t, t, 1.0);
+    t = v * sqrt(t);
+    return (v == 0.0 || v > 1.79769313486231570e+308 || w > 1.79769313486231570e+308) ? v + w : t;
+}
+static inline float s_fromMag(float m) { return m; }
+static inline double d_fromMag(double m) { return m; }
+static inline orc_cfloat c_fromMag(float m) { orc_cfloat r = {m, 0.0f}; return r; }
+static inline orc_cdouble z_fromMag(double m) { orc_cdouble r = {m, 0.0}; return r; }
+static inline int s_isOne(float a) { return a == 1.0f; }
+static inline int d_isOne(double a) { return a == 1.0; }
+static inline int c_isOne(orc_cfloat a) { return a.x == 1.0f && a.y == 0.0f; }
+static inline int z_isOne(orc_cdouble a) { return a.x == 1.0 && a.y == 0.0; }
+
+#define ORC_DEFINE_LEVEL1(P, T, R)                                                                            \
+    void orc_##P##scal(T* y, int n, T alpha, const T* x)                                                      \
+    {                                                                                                         \
+        for (int i = 0; i < n; ++i)                                                                           \
+            y[i] = P##_mul(alpha, x[i]);                                                                      \
+    }                                                                                                         \
+    void orc_##P##abs(T* y, int n, T alpha, const T* x)                                                       \
+    {                                                                                                         \
+        for (int i = 0; i < n; ++i) {                                                                         \
+            const T m = P##_fromMag(P##_mag(x[i]));                                                           \
+            y[i] = P##_isOne(alpha) ? m : P##_mul(alpha, m);                                                  \
+        }                                                                                                     \
+    }                                                                                                         \
+    void orc_##P##axy(T* z, int n, T alpha, const T* x, const T* y)                                           \
+    {                                                                                                         \
+        for (int i = 0; i < n; ++i)                                                                           \
+            z[i] = P##_mul(alpha, P##_mul(x[i], y[i]));                                                       \
+    }                                                                                                         \
+    void orc_##P##axypbz(T* w, int n, T beta, const T* z, T alpha, const T* x, const T* y)                    \
+    {                                                                                                         \
+        for (int i = 0; i < n; ++i) {                                                                         \
+            if (!P##_nz(alpha))                                                                               \
+                w[i] = P##_mul(beta, z[i]);                                                                   \
+            else if (!P##_nz(beta))                                                                           \
+                w[i] = P##_mul(alpha, P##_mul(x[i], y[i]));                                                   \
+            else                                                                                              \
+                w[i] = P##_fma(alpha, P##_mul(x[i], y[i]), P##_mul(beta, z[i]));                              \
+        }                                                                                                     \
+    }                                                                                                         \
+    void orc_##P##gath(T* xValues, int xNnz, const int* xIndices, int base, const T* y)                       \
+    {                                                                                                         \
+        for (int i = 0; i < xNnz; ++i)                                                                        \
+            if (xIndices[i] - base >= 0)                                                                      \
+                xValues[i] = y[xIndices[i] - base];                                                           \
+    }                                                                                                         \
+    void orc_##P##scat(T* y, int xNnz, const T* xValues, const int* xIndices, int base, T beta)               \
+    {                                                                                                         \
+        for (int i = 0; i < xNnz; ++i) {                                                                      \
+            const int pos = xIndices[i] - base;                                                               \
+            if (pos < 0)                                                                                      \
+                continue;                                                                                     \
+            y[pos] = P##_nz(beta) ? P##_fma(beta, y[pos], xValues[i]) : xValues[i];                           \
+        }                                                                                                     \
+    }                                                                                                         \
+    void orc_##P##setscal(int first, int last, int base, T val, T* y)                                         \
+    {                                                                                                         \
+        for (int i = first - base; i <= last - base; ++i)                                                     \
+            y[i] = val;                                                                                       \
+    }                                                                                                         \
+    void orc_##P##asum(R* out, int n, const T* x)                                                             \
+    {                                                                                                         \
+        R acc = 0;                                                                                            \
+        for (int i = 0; i < n; ++i)                                                                           \
+            acc += P##_mag(x[i]);                                                                             \
+        *out = acc;                                                                                           \
+    }                                                                                                         \
+    void orc_##P##amax(R* out, int n, const T* x)                                                             \
+    {                                                                                                         \
+        R acc = 0;                                                                                            \
+        for (int i = 0; i < n; ++i)                                                                           \
+            if (P##_mag(x[i]) > acc)                                                                          \
+                acc = P##_mag(x[i]);                                                                          \
+        *out = acc;                                                                                           \
+    }
+
+ORC_DEFINE_LEVEL1(s, float, float)
+ORC_DEFINE_LEVEL1(d, double, double)
+ORC_DEFINE_LEVEL1(c, orc_cfloat, float)
+ORC_DEFINE_LEVEL1(z, orc_cdouble, double)
+
+/* integer flavours: gath_base.cuh / scat_base.cuh / setscal_base.cuh with VALUE_TYPE int (igath.cu, iscat.cu, isetscal.cu) */
+void orc_igath(int* xValues, int xNnz, const int* xIndices, int base, const int* y)
+{
+    for (int i = 0; i < xNnz; ++i)
+        if (xIndices[i] - base >= 0)
+            xValues[i] = y[xIndices[i] - base];
+}
+void orc_iscat(int* y, int xNnz, const int* xValues, const int* xIndices, int base, int beta)
+{
+    for (int i = 0; i < xNnz; ++i) {
+        const int pos = xIndices[i] - base;
+        if (pos >= 0)
+            y[pos] = beta != 0 ? beta * y[pos] + xValues[i] : xValues[i];
+    }
+}
+void orc_isetscal(int first, int last, int base, int val, int* y)
+{
+    for (int i = first - base; i <= last - base; ++i)
+        y[i] = val;
 }
 
 /* Multi-vector SpMM oracle for the row-sharded path (NEW operation, not in the

@@ -113,6 +113,26 @@ for _L, _T in SCALAR.items():
     nrm2[_L] = _decl(f"spgpu{_L}nrm2", REAL[_L], [Handle, i32, ptr])
     mnrm2[_L] = _decl(f"spgpu{_L}mnrm2", None, [Handle, ptr, i32, ptr, i32, i32])
 
+# ---- vector.h, second half: the rest of the reference's Level-1 ----------------------
+scal, vabs, axy, maxy, axypbz, maxypbz, gath, scat, setscal = {}, {}, {}, {}, {}, {}, {}, {}, {}
+asum, amax, masum, mamax = {}, {}, {}, {}
+for _L, _T in list(SCALAR.items()) + [("I", C.c_int)]:
+    gath[_L] = _decl(f"spgpu{_L}gath", None, [Handle, ptr, i32, ptr, i32, ptr])
+    scat[_L] = _decl(f"spgpu{_L}scat", None, [Handle, ptr, i32, ptr, ptr, i32, _T])
+    setscal[_L] = _decl(f"spgpu{_L}setscal", None, [Handle, i32, i32, i32, _T, ptr])
+    if _L == "I":
+        continue
+    scal[_L] = _decl(f"spgpu{_L}scal", None, [Handle, ptr, i32, _T, ptr])
+    vabs[_L] = _decl(f"spgpu{_L}abs", None, [Handle, ptr, i32, _T, ptr])
+    axy[_L] = _decl(f"spgpu{_L}axy", None, [Handle, ptr, i32, _T, ptr, ptr])
+    maxy[_L] = _decl(f"spgpu{_L}maxy", None, [Handle, ptr, i32, _T, ptr, ptr, i32, i32])
+    axypbz[_L] = _decl(f"spgpu{_L}axypbz", None, [Handle, ptr, i32, _T, ptr, _T, ptr, ptr])
+    maxypbz[_L] = _decl(f"spgpu{_L}maxypbz", None, [Handle, ptr, i32, _T, ptr, _T, ptr, ptr, i32, i32])
+    asum[_L] = _decl(f"spgpu{_L}asum", REAL[_L], [Handle, i32, ptr])
+    amax[_L] = _decl(f"spgpu{_L}amax", REAL[_L], [Handle, i32, ptr])
+    masum[_L] = _decl(f"spgpu{_L}masum", None, [Handle, ptr, i32, ptr, i32, i32])
+    mamax[_L] = _decl(f"spgpu{_L}mamax", None, [Handle, ptr, i32, ptr, i32, i32])
+
 # ---- spmm.h (new: multi-vector product of the row-sharded path) ---------------------
 hellspmm, mv_interleave, mv_deinterleave = {}, {}, {}
 for _L in "SD":

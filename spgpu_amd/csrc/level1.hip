@@ -1,9 +1,12 @@
 /*
  * Level-1 operations next to SpMV on the hot path, for gfx950 (MI355X).
  *
- * C ABI: spgpu{S,D,C,Z}axpby / maxpby / dot / mdot / nrm2 / mnrm2
- *        (include/spgpu/vector.h; reference vector.h, kernels/{s,d,c,z}axpby.cu,
- *         kernels/{s,d,c,z}dot.cu, kernels/{s,d,c,z}nrm2.cu).
+ * C ABI: spgpu{S,D,C,Z}axpby / maxpby / dot / mdot / nrm2 / mnrm2 (hot path) and the rest of
+ *        the reference's vector.h: scal, abs, axy, axypbz (+m forms), gath, scat, setscal (+I),
+ *        asum, amax (+m forms)
+ *        (include/spgpu/vector.h; reference vector.h, kernels/{s,d,c,z}axpby.cu, {s,d,c,z}dot.cu,
+ *         {s,d,c,z}nrm2.cu, scal_base.cuh, abs_base.cuh, axy_base.cuh, gath_base.cuh, scat_base.cuh,
+ *         setscal_base.cuh, asum_base.cuh, amax_base.cuh).
  *
  * axpby is a pure stream (2 reads + 1 write per element, 1 read when beta==0):
  * 16-byte accesses per lane, a capped grid with a grid-stride loop, one launch
@@ -134,19 +137,44 @@ static void axpbyLaunch(spgpuHandle_t handle, ApiT* zApi, int n, ApiT betaApi, A
 
 /* ---- reductions ------------------------------------------------------------ */
 
-/* DOT: a[i]*b[i] accumulated with the SpMV multiply-add (un-conjugated);
- * NRM2: |a[i]|^2 accumulated in the real type. */
+/* DOT : a[i]*b[i] accumulated with the SpMV multiply-add (un-conjugated, zdot.cu:54)
+ * NRM2: |a[i]|^2 accumulated in the real type (dnrm2.cu:52-53)
+ * ASUM: |a[i]| added; AMAX: max |a[i]|  (|.| of a complex value as cuCabs) */
+enum ReduceMode { kDot = 0, kNrm2 = 1, kAsum = 2, kAmax = 3 };
+
 template <typename T> struct RealOf { using type = T; };
 template <typename R> struct RealOf<Cx<R>> { using type = R; };
 
 template <typename R> __device__ inline R absSqAdd(R v, R acc) { return mulAdd(v, v, acc); }
 template <typename R> __device__ inline R absSqAdd(Cx<R> v, R acc) { return mulAdd(v.y, v.y, mulAdd(v.x, v.x, acc)); }
 
-template <typename A> __device__ inline A blockSum(A v, A* lds)
+/* cuCabs / cuCabsf: v*sqrt(1 + (w/v)^2) with v = max(|re|,|im|), w = min; 1 + t*t is one fma. */
+__device__ inline float magnitude(float v) { return __builtin_fabsf(v); }
+__device__ inline double magnitude(double v) { return __builtin_fabs(v); }
+template <typename R> __device__ inline R magnitude(Cx<R> z)
+{
+    const R a = magnitude(z.x), b = magnitude(z.y);
+    const R v = a > b ? a : b, w = a > b ? b : a;
+    R t = w / v;
+    t = mulAdd(t, t, R(1));
+    t = v * (sizeof(R) == 4 ? (R)__builtin_sqrtf((float)t) : (R)__builtin_sqrt((double)t));
+    const R huge = sizeof(R) == 4 ? (R)3.402823466e38f : (R)1.79769313486231570e+308;
+    return (v == R(0) || v > huge || w > huge) ? v + w : t;
+}
+
+template <int MODE, typename A> __device__ __host__ inline A combine(A x, A y)
+{
+    if constexpr (MODE == kAmax)
+        return y > x ? y : x;
+    else
+        return add(x, y);
+}
+
+template <int MODE, typename A> __device__ inline A blockCombine(A v, A* lds)
 {
 #pragma unroll
     for (int m = 1; m < kWave; m <<= 1)
-        v = add(v, laneXor(v, m));
+        v = combine<MODE>(v, laneXor(v, m));
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & (kWave - 1)) == 0)
         lds[wave] = v;
@@ -154,20 +182,37 @@ template <typename A> __device__ inline A blockSum(A v, A* lds)
     A total = lds[0];
 #pragma unroll
     for (int w = 1; w < kL1Threads / kWave; ++w)
-        total = add(total, lds[w]);
+        total = combine<MODE>(total, lds[w]);
     return total;
 }
 
-template <typename T, int VEC, bool NRM2>
-__global__ __launch_bounds__(kL1Threads) void reduceKernel(typename std::conditional<NRM2, typename RealOf<T>::type, T>::type* partials,
-                                                          int n, const T* a, const T* b, long long pitch)
+template <typename T, int MODE> struct AccOf { using type = typename RealOf<T>::type; };
+template <typename T> struct AccOf<T, kDot> { using type = T; };
+
+template <int MODE, typename T, typename Acc> __device__ inline Acc accumulate(T a, T b, Acc acc)
 {
-    using Acc = typename std::conditional<NRM2, typename RealOf<T>::type, T>::type;
+    if constexpr (MODE == kDot)
+        return mulAdd(a, b, acc);
+    else if constexpr (MODE == kNrm2)
+        return absSqAdd(a, acc);
+    else if constexpr (MODE == kAsum)
+        return acc + magnitude(a);
+    else {
+        const Acc m = magnitude(a);
+        return m > acc ? m : acc;
+    }
+}
+
+template <typename T, int VEC, int MODE>
+__global__ __launch_bounds__(kL1Threads) void reduceKernel(typename AccOf<T, MODE>::type* partials, int n, const T* a,
+                                                          const T* b, long long pitch)
+{
+    using Acc = typename AccOf<T, MODE>::type;
     __shared__ Acc lds[kL1Threads / kWave];
 
     const long long shift = (long long)blockIdx.y * pitch;
     a += shift;
-    if constexpr (!NRM2)
+    if constexpr (MODE == kDot)
         b += shift;
 
     Acc acc = zeroOf<Acc>();
@@ -182,41 +227,37 @@ __global__ __launch_bounds__(kL1Threads) void reduceKernel(typename std::conditi
             live[u] = p < packs;
             if (live[u]) {
                 av[u] = loadPack<false, T, VEC>(a + p * VEC);
-                if constexpr (!NRM2)
+                if constexpr (MODE == kDot)
                     bv[u] = loadPack<false, T, VEC>(b + p * VEC);
+                else
+                    bv[u] = av[u];
             }
         }
 #pragma unroll
         for (int u = 0; u < kL1Unroll; ++u) {
             if (live[u]) {
 #pragma unroll
-                for (int t = 0; t < VEC; ++t) {
-                    if constexpr (NRM2)
-                        acc = absSqAdd(av[u].v[t], acc);
-                    else
-                        acc = mulAdd(av[u].v[t], bv[u].v[t], acc);
-                }
+                for (int t = 0; t < VEC; ++t)
+                    acc = accumulate<MODE>(av[u].v[t], bv[u].v[t], acc);
             }
         }
     }
     const long long tail = packs * VEC + (long long)blockIdx.x * kL1Threads + threadIdx.x;
-    if (tail < n) {
-        if constexpr (NRM2)
-            acc = absSqAdd(a[tail], acc);
-        else
-            acc = mulAdd(a[tail], b[tail], acc);
-    }
+    if (tail < n)
+        acc = accumulate<MODE>(a[tail], MODE == kDot ? b[tail] : a[tail], acc);
 
-    const Acc total = blockSum(acc, lds);
+    const Acc total = blockCombine<MODE>(acc, lds);
     if (threadIdx.x == 0)
         partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total;
 }
 
 /* Runs the two-stage reduction for `count` vectors and leaves one host value
  * per vector in out[].  Synchronises handle->currentStream. */
-template <typename T, bool NRM2, typename Acc>
-static void reduceVectors(spgpuHandle_t handle, Acc* out, int n, const T* a, const T* b, int count, int pitch)
+template <typename T, int MODE>
+static void reduceVectors(spgpuHandle_t handle, typename AccOf<T, MODE>::type* out, int n, const T* a, const T* b,
+                          int count, int pitch)
 {
+    using Acc = typename AccOf<T, MODE>::type;
     for (int j = 0; j < count; ++j)
         out[j] = zeroOf<Acc>();
     if (n <= 0 || count <= 0)
@@ -233,8 +274,8 @@ static void reduceVectors(spgpuHandle_t handle, Acc* out, int n, const T* a, con
     for (int first = 0; first < count; first += maxVectorsPerPass) {
         const int vectors = count - first < maxVectorsPerPass ? count - first : maxVectorsPerPass;
         const T* a0 = a + (size_t)first * pitch;
-        const T* b0 = NRM2 ? nullptr : b + (size_t)first * pitch;
-        const bool wide = WIDE > 1 && ((uintptr_t)a0 % 16 == 0) && (NRM2 || (uintptr_t)b0 % 16 == 0) &&
+        const T* b0 = MODE == kDot ? b + (size_t)first * pitch : nullptr;
+        const bool wide = WIDE > 1 && ((uintptr_t)a0 % 16 == 0) && (MODE != kDot || (uintptr_t)b0 % 16 == 0) &&
                           (vectors == 1 || pitch % WIDE == 0);
         const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
         long long blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
@@ -244,28 +285,233 @@ static void reduceVectors(spgpuHandle_t handle, Acc* out, int n, const T* a, con
         const dim3 grid((unsigned)blocks, (unsigned)vectors);
 
         if (wide)
-            hipLaunchKernelGGL((reduceKernel<T, WIDE, NRM2>), grid, dim3(kL1Threads), 0, s, dev, n, a0, b0,
+            hipLaunchKernelGGL((reduceKernel<T, WIDE, MODE>), grid, dim3(kL1Threads), 0, s, dev, n, a0, b0,
                                (long long)pitch);
         else
-            hipLaunchKernelGGL((reduceKernel<T, 1, NRM2>), grid, dim3(kL1Threads), 0, s, dev, n, a0, b0,
+            hipLaunchKernelGGL((reduceKernel<T, 1, MODE>), grid, dim3(kL1Threads), 0, s, dev, n, a0, b0,
                                (long long)pitch);
         (void)hipMemcpyAsync(host, dev, sizeof(Acc) * (size_t)blocks * vectors, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
 
         for (int j = 0; j < vectors; ++j) {
             Acc total = zeroOf<Acc>();
-            for (long long k = 0; k < blocks; ++k) {
-                total = add(total, host[(size_t)j * blocks + k]);
-            }
+            for (long long k = 0; k < blocks; ++k)
+                total = combine<MODE>(total, host[(size_t)j * blocks + k]);
             out[first + j] = total;
         }
     }
-    spgpuDebugCheck(handle, NRM2 ? "nrm2" : "dot");
+    spgpuDebugCheck(handle, "reduction");
+}
+
+/* ---- element-wise maps: scal, abs, axy, axypbz -------------------------------
+ * One kernel shape (16-byte accesses, kL1Unroll in flight per lane, tile-stride loop,
+ * grid.y = vector of a multivector); the operation is a compile-time tag.
+ *   kScal   : out = alpha * x                               (scal_base.cuh:34-45)
+ *   kAbs    : out = alpha * |x|   (complex: alpha * (|x|,0); alpha == 1 -> |x|)   (abs_base.cuh:43-70)
+ *   kAxy    : out = alpha * (x*y)                           (axy_base.cuh:37-47)
+ *   kAxypbz : out = fma(alpha, x*y, beta*z)                 (axy_base.cuh:95-108) */
+enum MapOp { kScal = 0, kAbs = 1, kAxy = 2, kAxypbz = 3 };
+
+__device__ inline float fromMagnitude(float m, float) { return m; }
+__device__ inline double fromMagnitude(double m, double) { return m; }
+template <typename R> __device__ inline Cx<R> fromMagnitude(R m, Cx<R>) { return Cx<R>{m, R(0)}; }
+
+template <int OP, typename T> __device__ inline T mapOne(T alpha, T beta, T x, T y, T z, bool alphaIsOne)
+{
+    if constexpr (OP == kScal)
+        return mul(alpha, x);
+    else if constexpr (OP == kAbs) {
+        const T m = fromMagnitude(magnitude(x), x);
+        return alphaIsOne ? m : mul(alpha, m);
+    } else if constexpr (OP == kAxy)
+        return mul(alpha, mul(x, y));
+    else
+        return mulAdd(alpha, mul(x, y), mul(beta, z));
+}
+
+template <typename T, int VEC, int OP>
+__global__ __launch_bounds__(kL1Threads) void mapKernel(T* out, int n, T alpha, T beta, const T* x, const T* y, const T* z,
+                                                       long long pitch, int alphaIsOne)
+{
+    const long long shift = (long long)blockIdx.y * pitch;
+    out += shift;
+    x += shift;
+    if constexpr (OP >= kAxy)
+        y += shift;
+    if constexpr (OP == kAxypbz)
+        z += shift;
+
+    const long long packs = n / VEC;
+    constexpr long long TILE = (long long)kL1Threads * kL1Unroll;
+    for (long long base = (long long)blockIdx.x * TILE; base < packs; base += (long long)gridDim.x * TILE) {
+        Pack<T, VEC> xv[kL1Unroll], yv[kL1Unroll], zv[kL1Unroll];
+#pragma unroll
+        for (int u = 0; u < kL1Unroll; ++u) {
+            const long long p = base + u * kL1Threads + threadIdx.x;
+            if (p < packs) {
+                xv[u] = loadPack<false, T, VEC>(x + p * VEC);
+                if constexpr (OP >= kAxy)
+                    yv[u] = loadPack<false, T, VEC>(y + p * VEC);
+                else
+                    yv[u] = xv[u];
+                if constexpr (OP == kAxypbz)
+                    zv[u] = loadPack<false, T, VEC>(z + p * VEC);
+                else
+                    zv[u] = xv[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kL1Unroll; ++u) {
+            const long long p = base + u * kL1Threads + threadIdx.x;
+            if (p < packs) {
+                Pack<T, VEC> o;
+#pragma unroll
+                for (int t = 0; t < VEC; ++t)
+                    o.v[t] = mapOne<OP>(alpha, beta, xv[u].v[t], yv[u].v[t], zv[u].v[t], alphaIsOne != 0);
+                storePack<T, VEC>(out + p * VEC, o);
+            }
+        }
+    }
+    const long long tail = packs * VEC + (long long)blockIdx.x * kL1Threads + threadIdx.x;
+    if (tail < n)
+        out[tail] = mapOne<OP>(alpha, beta, x[tail], OP >= kAxy ? y[tail] : x[tail], OP == kAxypbz ? z[tail] : x[tail],
+                               alphaIsOne != 0);
+}
+
+template <typename T, int OP, typename ApiT>
+static void mapLaunch(spgpuHandle_t handle, ApiT* outApi, int n, ApiT alphaApi, ApiT betaApi, const ApiT* xApi,
+                      const ApiT* yApi, const ApiT* zApi, int count, int pitch)
+{
+    static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
+    if (n <= 0 || count <= 0)
+        return;
+    T* out = reinterpret_cast<T*>(outApi);
+    const T *x = reinterpret_cast<const T*>(xApi), *y = reinterpret_cast<const T*>(yApi), *z = reinterpret_cast<const T*>(zApi);
+    T alpha, beta, one = zeroOf<T>();
+    __builtin_memcpy(&alpha, &alphaApi, sizeof(T));
+    __builtin_memcpy(&beta, &betaApi, sizeof(T));
+    using R = typename RealOf<T>::type;
+    const R unit = R(1);
+    __builtin_memcpy(&one, &unit, sizeof(R)); /* (1) or (1, 0) */
+    const int alphaIsOne = __builtin_memcmp(&alpha, &one, sizeof(T)) == 0;
+
+    constexpr int WIDE = 16 / (int)sizeof(T);
+    const bool wide = WIDE > 1 && ((uintptr_t)out % 16 == 0) && ((uintptr_t)x % 16 == 0) &&
+                      (OP < kAxy || (uintptr_t)y % 16 == 0) && (OP != kAxypbz || (uintptr_t)z % 16 == 0) &&
+                      (count == 1 || pitch % WIDE == 0);
+    const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
+    long long blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
+    const long long cap = kL1MaxBlocks / (count < kL1MaxBlocks ? count : kL1MaxBlocks);
+    if (blocks > (cap > 1 ? cap : 1))
+        blocks = cap > 1 ? cap : 1;
+    const dim3 grid((unsigned)blocks, (unsigned)count);
+    hipStream_t s = handle->currentStream;
+    if (wide)
+        hipLaunchKernelGGL((mapKernel<T, WIDE, OP>), grid, dim3(kL1Threads), 0, s, out, n, alpha, beta, x, y, z,
+                           (long long)pitch, alphaIsOne);
+    else
+        hipLaunchKernelGGL((mapKernel<T, 1, OP>), grid, dim3(kL1Threads), 0, s, out, n, alpha, beta, x, y, z,
+                           (long long)pitch, alphaIsOne);
+    spgpuDebugCheck(handle, "level-1 map");
+}
+
+/* axypbz dispatch of the reference (axy_base.cuh:139-176): alpha == 0 -> scal(beta, z); beta == 0 -> axy. */
+template <typename T, typename ApiT>
+static void axypbz(spgpuHandle_t h, ApiT* w, int n, ApiT beta, ApiT* z, ApiT alpha, ApiT* x, ApiT* y, int count, int pitch)
+{
+    T a, b;
+    __builtin_memcpy(&a, &alpha, sizeof(T));
+    __builtin_memcpy(&b, &beta, sizeof(T));
+    if (!isNotZero(a))
+        mapLaunch<T, kScal>(h, w, n, beta, beta, z, z, z, count, pitch);
+    else if (!isNotZero(b))
+        mapLaunch<T, kAxy>(h, w, n, alpha, alpha, x, y, y, count, pitch);
+    else
+        mapLaunch<T, kAxypbz>(h, w, n, alpha, beta, x, y, z, count, pitch);
+}
+
+/* ---- gather / scatter / fill ---------------------------------------------------- */
+template <typename T> __device__ inline T scatCombine(T beta, T y, T v) { return mulAdd(beta, y, v); }
+template <> __device__ inline int scatCombine<int>(int beta, int y, int v) { return beta * y + v; }
+__device__ inline bool isNotZero(int a) { return a != 0; }
+
+template <typename T>
+__global__ __launch_bounds__(kL1Threads) void gathKernel(T* values, int count, const int* indices, int firstIndex, const T* vector)
+{
+    const long long stride = (long long)gridDim.x * kL1Threads;
+    for (long long i = (long long)blockIdx.x * kL1Threads + threadIdx.x; i < count; i += stride) {
+        const int pos = indices[i] - firstIndex;
+        if (pos >= 0)
+            values[i] = vector[pos];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kL1Threads) void scatKernel(T* vector, int count, const int* indices, const T* values, int firstIndex, T beta)
+{
+    const bool hasBeta = isNotZero(beta);
+    const long long stride = (long long)gridDim.x * kL1Threads;
+    for (long long i = (long long)blockIdx.x * kL1Threads + threadIdx.x; i < count; i += stride) {
+        const int pos = indices[i] - firstIndex;
+        if (pos >= 0)
+            vector[pos] = hasBeta ? scatCombine(beta, vector[pos], values[i]) : values[i];
+    }
+}
+
+template <typename T> __global__ __launch_bounds__(kL1Threads) void fillKernel(T* vector, long long count, T value)
+{
+    const long long stride = (long long)gridDim.x * kL1Threads;
+    for (long long i = (long long)blockIdx.x * kL1Threads + threadIdx.x; i < count; i += stride)
+        vector[i] = value;
+}
+
+static unsigned sparseGrid(long long count)
+{
+    long long blocks = (count + kL1Threads - 1) / kL1Threads;
+    return (unsigned)(blocks > 4 * kL1MaxBlocks ? 4 * kL1MaxBlocks : (blocks < 1 ? 1 : blocks));
+}
+
+template <typename T, typename ApiT>
+static void gath(spgpuHandle_t h, ApiT* xValues, int xNnz, const int* xIndices, int xBaseIndex, const ApiT* y)
+{
+    if (xNnz <= 0)
+        return;
+    hipLaunchKernelGGL((gathKernel<T>), dim3(sparseGrid(xNnz)), dim3(kL1Threads), 0, h->currentStream,
+                       reinterpret_cast<T*>(xValues), xNnz, xIndices, xBaseIndex, reinterpret_cast<const T*>(y));
+    spgpuDebugCheck(h, "gath");
+}
+
+template <typename T, typename ApiT>
+static void scat(spgpuHandle_t h, ApiT* y, int xNnz, const ApiT* xValues, const int* xIndices, int xBaseIndex, ApiT betaApi)
+{
+    if (xNnz <= 0)
+        return;
+    T beta;
+    __builtin_memcpy(&beta, &betaApi, sizeof(T));
+    hipLaunchKernelGGL((scatKernel<T>), dim3(sparseGrid(xNnz)), dim3(kL1Threads), 0, h->currentStream,
+                       reinterpret_cast<T*>(y), xNnz, xIndices, reinterpret_cast<const T*>(xValues), xBaseIndex, beta);
+    spgpuDebugCheck(h, "scat");
+}
+
+template <typename T, typename ApiT>
+static void setscal(spgpuHandle_t h, int first, int last, int baseIndex, ApiT valApi, ApiT* y)
+{
+    const long long n = (long long)last - first + 1;
+    if (n <= 0)
+        return;
+    T val;
+    __builtin_memcpy(&val, &valApi, sizeof(T));
+    hipLaunchKernelGGL((fillKernel<T>), dim3(sparseGrid(n)), dim3(kL1Threads), 0, h->currentStream,
+                       reinterpret_cast<T*>(y) + (first - baseIndex), n, val);
+    spgpuDebugCheck(h, "setscal");
 }
 
 } // namespace spgpu
 
 using namespace spgpu;
+
+#define SPGPU_CF(p) reinterpret_cast<cfloat*>(p)
+#define SPGPU_CD(p) reinterpret_cast<cdouble*>(p)
 
 extern "C" {
 
@@ -294,66 +540,87 @@ void spgpuZmaxpby(spgpuHandle_t h, hipDoubleComplex* z, int n, hipDoubleComplex 
 
 /* ---- dot ---- */
 float spgpuSdot(spgpuHandle_t h, int n, float* a, float* b)
-{ float r; reduceVectors<float, false>(h, &r, n, a, b, 1, 0); return r; }
+{ float r; reduceVectors<float, kDot>(h, &r, n, a, b, 1, 0); return r; }
 double spgpuDdot(spgpuHandle_t h, int n, double* a, double* b)
-{ double r; reduceVectors<double, false>(h, &r, n, a, b, 1, 0); return r; }
+{ double r; reduceVectors<double, kDot>(h, &r, n, a, b, 1, 0); return r; }
 hipFloatComplex spgpuCdot(spgpuHandle_t h, int n, hipFloatComplex* a, hipFloatComplex* b)
 {
     cfloat r;
-    reduceVectors<cfloat, false>(h, &r, n, reinterpret_cast<cfloat*>(a), reinterpret_cast<cfloat*>(b), 1, 0);
+    reduceVectors<cfloat, kDot>(h, &r, n, SPGPU_CF(a), SPGPU_CF(b), 1, 0);
     return make_hipFloatComplex(r.x, r.y);
 }
 hipDoubleComplex spgpuZdot(spgpuHandle_t h, int n, hipDoubleComplex* a, hipDoubleComplex* b)
 {
     cdouble r;
-    reduceVectors<cdouble, false>(h, &r, n, reinterpret_cast<cdouble*>(a), reinterpret_cast<cdouble*>(b), 1, 0);
+    reduceVectors<cdouble, kDot>(h, &r, n, SPGPU_CD(a), SPGPU_CD(b), 1, 0);
     return make_hipDoubleComplex(r.x, r.y);
 }
-
 void spgpuSmdot(spgpuHandle_t h, float* y, int n, float* a, float* b, int count, int pitch)
-{ reduceVectors<float, false>(h, y, n, a, b, count, pitch); }
+{ reduceVectors<float, kDot>(h, y, n, a, b, count, pitch); }
 void spgpuDmdot(spgpuHandle_t h, double* y, int n, double* a, double* b, int count, int pitch)
-{ reduceVectors<double, false>(h, y, n, a, b, count, pitch); }
+{ reduceVectors<double, kDot>(h, y, n, a, b, count, pitch); }
 void spgpuCmdot(spgpuHandle_t h, hipFloatComplex* y, int n, hipFloatComplex* a, hipFloatComplex* b, int count, int pitch)
-{
-    reduceVectors<cfloat, false>(h, reinterpret_cast<cfloat*>(y), n, reinterpret_cast<cfloat*>(a),
-                                 reinterpret_cast<cfloat*>(b), count, pitch);
-}
+{ reduceVectors<cfloat, kDot>(h, SPGPU_CF(y), n, SPGPU_CF(a), SPGPU_CF(b), count, pitch); }
 void spgpuZmdot(spgpuHandle_t h, hipDoubleComplex* y, int n, hipDoubleComplex* a, hipDoubleComplex* b, int count, int pitch)
-{
-    reduceVectors<cdouble, false>(h, reinterpret_cast<cdouble*>(y), n, reinterpret_cast<cdouble*>(a),
-                                  reinterpret_cast<cdouble*>(b), count, pitch);
-}
+{ reduceVectors<cdouble, kDot>(h, SPGPU_CD(y), n, SPGPU_CD(a), SPGPU_CD(b), count, pitch); }
 
-/* ---- nrm2 ---- */
-float spgpuSnrm2(spgpuHandle_t h, int n, float* x)
-{ float r; reduceVectors<float, true>(h, &r, n, x, (const float*)nullptr, 1, 0); return sqrtf(r); }
-double spgpuDnrm2(spgpuHandle_t h, int n, double* x)
-{ double r; reduceVectors<double, true>(h, &r, n, x, (const double*)nullptr, 1, 0); return sqrt(r); }
-float spgpuCnrm2(spgpuHandle_t h, int n, hipFloatComplex* x)
-{ float r; reduceVectors<cfloat, true>(h, &r, n, reinterpret_cast<cfloat*>(x), (const cfloat*)nullptr, 1, 0); return sqrtf(r); }
-double spgpuZnrm2(spgpuHandle_t h, int n, hipDoubleComplex* x)
-{ double r; reduceVectors<cdouble, true>(h, &r, n, reinterpret_cast<cdouble*>(x), (const cdouble*)nullptr, 1, 0); return sqrt(r); }
+/* ---- nrm2 / asum / amax ---- */
+#define SPGPU_REAL_REDUCTION(NAME, MODE, FINISH_F, FINISH_D)                                                              \
+    float spgpuS##NAME(spgpuHandle_t h, int n, float* x)                                                                  \
+    { float r; reduceVectors<float, MODE>(h, &r, n, x, (const float*)nullptr, 1, 0); return FINISH_F(r); }                \
+    double spgpuD##NAME(spgpuHandle_t h, int n, double* x)                                                                \
+    { double r; reduceVectors<double, MODE>(h, &r, n, x, (const double*)nullptr, 1, 0); return FINISH_D(r); }             \
+    float spgpuC##NAME(spgpuHandle_t h, int n, hipFloatComplex* x)                                                        \
+    { float r; reduceVectors<cfloat, MODE>(h, &r, n, SPGPU_CF(x), (const cfloat*)nullptr, 1, 0); return FINISH_F(r); }    \
+    double spgpuZ##NAME(spgpuHandle_t h, int n, hipDoubleComplex* x)                                                      \
+    { double r; reduceVectors<cdouble, MODE>(h, &r, n, SPGPU_CD(x), (const cdouble*)nullptr, 1, 0); return FINISH_D(r); } \
+    void spgpuSm##NAME(spgpuHandle_t h, float* y, int n, float* x, int count, int pitch)                                  \
+    { reduceVectors<float, MODE>(h, y, n, x, (const float*)nullptr, count, pitch); for (int j = 0; j < count; ++j) y[j] = FINISH_F(y[j]); } \
+    void spgpuDm##NAME(spgpuHandle_t h, double* y, int n, double* x, int count, int pitch)                                \
+    { reduceVectors<double, MODE>(h, y, n, x, (const double*)nullptr, count, pitch); for (int j = 0; j < count; ++j) y[j] = FINISH_D(y[j]); } \
+    void spgpuCm##NAME(spgpuHandle_t h, float* y, int n, hipFloatComplex* x, int count, int pitch)                        \
+    { reduceVectors<cfloat, MODE>(h, y, n, SPGPU_CF(x), (const cfloat*)nullptr, count, pitch); for (int j = 0; j < count; ++j) y[j] = FINISH_F(y[j]); } \
+    void spgpuZm##NAME(spgpuHandle_t h, double* y, int n, hipDoubleComplex* x, int count, int pitch)                      \
+    { reduceVectors<cdouble, MODE>(h, y, n, SPGPU_CD(x), (const cdouble*)nullptr, count, pitch); for (int j = 0; j < count; ++j) y[j] = FINISH_D(y[j]); }
 
-void spgpuSmnrm2(spgpuHandle_t h, float* y, int n, float* x, int count, int pitch)
-{
-    reduceVectors<float, true>(h, y, n, x, (const float*)nullptr, count, pitch);
-    for (int j = 0; j < count; ++j) y[j] = sqrtf(y[j]);
-}
-void spgpuDmnrm2(spgpuHandle_t h, double* y, int n, double* x, int count, int pitch)
-{
-    reduceVectors<double, true>(h, y, n, x, (const double*)nullptr, count, pitch);
-    for (int j = 0; j < count; ++j) y[j] = sqrt(y[j]);
-}
-void spgpuCmnrm2(spgpuHandle_t h, float* y, int n, hipFloatComplex* x, int count, int pitch)
-{
-    reduceVectors<cfloat, true>(h, y, n, reinterpret_cast<cfloat*>(x), (const cfloat*)nullptr, count, pitch);
-    for (int j = 0; j < count; ++j) y[j] = sqrtf(y[j]);
-}
-void spgpuZmnrm2(spgpuHandle_t h, double* y, int n, hipDoubleComplex* x, int count, int pitch)
-{
-    reduceVectors<cdouble, true>(h, y, n, reinterpret_cast<cdouble*>(x), (const cdouble*)nullptr, count, pitch);
-    for (int j = 0; j < count; ++j) y[j] = sqrt(y[j]);
-}
+#define SPGPU_SAME(v) (v)
+SPGPU_REAL_REDUCTION(nrm2, kNrm2, sqrtf, sqrt)
+SPGPU_REAL_REDUCTION(asum, kAsum, SPGPU_SAME, SPGPU_SAME)
+SPGPU_REAL_REDUCTION(amax, kAmax, SPGPU_SAME, SPGPU_SAME)
+
+/* ---- scal / abs / axy / axypbz ---- */
+#define SPGPU_MAPS(L, T, ApiT)                                                                                            \
+    void spgpu##L##scal(spgpuHandle_t h, ApiT* y, int n, ApiT alpha, ApiT* x)                                             \
+    { mapLaunch<T, kScal>(h, y, n, alpha, alpha, x, x, x, 1, 0); }                                                        \
+    void spgpu##L##abs(spgpuHandle_t h, ApiT* y, int n, ApiT alpha, ApiT* x)                                              \
+    { mapLaunch<T, kAbs>(h, y, n, alpha, alpha, x, x, x, 1, 0); }                                                         \
+    void spgpu##L##axy(spgpuHandle_t h, ApiT* z, int n, ApiT alpha, ApiT* x, ApiT* y)                                     \
+    { mapLaunch<T, kAxy>(h, z, n, alpha, alpha, x, y, y, 1, 0); }                                                         \
+    void spgpu##L##maxy(spgpuHandle_t h, ApiT* z, int n, ApiT alpha, ApiT* x, ApiT* y, int count, int pitch)              \
+    { mapLaunch<T, kAxy>(h, z, n, alpha, alpha, x, y, y, count, pitch); }                                                 \
+    void spgpu##L##axypbz(spgpuHandle_t h, ApiT* w, int n, ApiT beta, ApiT* z, ApiT alpha, ApiT* x, ApiT* y)              \
+    { axypbz<T>(h, w, n, beta, z, alpha, x, y, 1, 0); }                                                                   \
+    void spgpu##L##maxypbz(spgpuHandle_t h, ApiT* w, int n, ApiT beta, ApiT* z, ApiT alpha, ApiT* x, ApiT* y, int count,  \
+                           int pitch)                                                                                     \
+    { axypbz<T>(h, w, n, beta, z, alpha, x, y, count, pitch); }                                                           \
+    void spgpu##L##gath(spgpuHandle_t h, ApiT* xValues, int xNnz, const int* xIndices, int xBaseIndex, const ApiT* y)     \
+    { gath<T>(h, xValues, xNnz, xIndices, xBaseIndex, y); }                                                               \
+    void spgpu##L##scat(spgpuHandle_t h, ApiT* y, int xNnz, const ApiT* xValues, const int* xIndices, int xBaseIndex,     \
+                        ApiT beta)                                                                                        \
+    { scat<T>(h, y, xNnz, xValues, xIndices, xBaseIndex, beta); }                                                         \
+    void spgpu##L##setscal(spgpuHandle_t h, int first, int last, int baseIndex, ApiT val, ApiT* y)                        \
+    { setscal<T>(h, first, last, baseIndex, val, y); }
+
+SPGPU_MAPS(S, float, float)
+SPGPU_MAPS(D, double, double)
+SPGPU_MAPS(C, cfloat, hipFloatComplex)
+SPGPU_MAPS(Z, cdouble, hipDoubleComplex)
+
+void spgpuIgath(spgpuHandle_t h, int* xValues, int xNnz, const int* xIndices, int xBaseIndex, const int* y)
+{ gath<int>(h, xValues, xNnz, xIndices, xBaseIndex, y); }
+void spgpuIscat(spgpuHandle_t h, int* y, int xNnz, const int* xValues, const int* xIndices, int xBaseIndex, int beta)
+{ scat<int>(h, y, xNnz, xValues, xIndices, xBaseIndex, beta); }
+void spgpuIsetscal(spgpuHandle_t h, int first, int last, int baseIndex, int val, int* y)
+{ setscal<int>(h, first, last, baseIndex, val, y); }
 
 } // extern "C"

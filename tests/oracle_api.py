@@ -249,3 +249,79 @@ def hell_spmm(hell, X, Y, alpha, beta, r_idx=None):
                                            hell["hack_size"], _p(hell["hack_offsets"]), _p(hell["row_lengths"]), _p(ri),
                                            hell["rows"], _p(X), scalar(L, beta), hell["base"], count, count, count)
     return Z
+
+
+# ---- rest of Level-1 ---------------------------------------------------------------------
+REAL_DTYPE = {"S": np.float32, "D": np.float64, "C": np.float32, "Z": np.float64}
+for _L, _T in SCALAR.items():
+    _l = _LOW[_L]
+    for _n, _a in (("scal", [ptr, i32, _T, ptr]), ("abs", [ptr, i32, _T, ptr]), ("axy", [ptr, i32, _T, ptr, ptr]),
+                   ("axypbz", [ptr, i32, _T, ptr, _T, ptr, ptr]), ("gath", [ptr, i32, ptr, i32, ptr]),
+                   ("scat", [ptr, i32, ptr, ptr, i32, _T]), ("setscal", [i32, i32, i32, _T, ptr]),
+                   ("asum", [ptr, i32, ptr]), ("amax", [ptr, i32, ptr])):
+        _f = getattr(orc, f"orc_{_l}{_n}")
+        _f.restype, _f.argtypes = None, _a
+orc.orc_igath.argtypes = [ptr, i32, ptr, i32, ptr]
+orc.orc_iscat.argtypes = [ptr, i32, ptr, ptr, i32, i32]
+orc.orc_isetscal.argtypes = [i32, i32, i32, i32, ptr]
+for _f in (orc.orc_igath, orc.orc_iscat, orc.orc_isetscal):
+    _f.restype = None
+
+
+def _dt(letter):
+    return np.int32 if letter == "I" else NP_DTYPE[letter]
+
+
+def _sc(letter, v):
+    return i32(int(v)) if letter == "I" else scalar(letter, v)
+
+
+def level1_map(letter, op, n, alpha, x, y=None, beta=None, z=None):
+    """op in scal / abs / axy / axypbz; returns the output vector."""
+    dt = NP_DTYPE[letter]
+    out = np.zeros(n, dt)
+    x = np.ascontiguousarray(x, dt)
+    fn = getattr(orc, f"orc_{_LOW[letter]}{op}")
+    if op in ("scal", "abs"):
+        fn(_p(out), n, scalar(letter, alpha), _p(x))
+    elif op == "axy":
+        fn(_p(out), n, scalar(letter, alpha), _p(x), _p(np.ascontiguousarray(y, dt)))
+    else:
+        fn(_p(out), n, scalar(letter, beta), _p(np.ascontiguousarray(z, dt)), scalar(letter, alpha), _p(x),
+           _p(np.ascontiguousarray(y, dt)))
+    return out
+
+
+def gath(letter, values_in, indices, base, y):
+    out = np.array(values_in, _dt(letter), copy=True)
+    idx = np.ascontiguousarray(indices, np.int32)
+    getattr(orc, f"orc_{letter.lower()}gath")(_p(out), idx.size, _p(idx), base, _p(np.ascontiguousarray(y, _dt(letter))))
+    return out
+
+
+def scat(letter, y_in, values, indices, base, beta):
+    out = np.array(y_in, _dt(letter), copy=True)
+    idx = np.ascontiguousarray(indices, np.int32)
+    getattr(orc, f"orc_{letter.lower()}scat")(_p(out), idx.size, _p(np.ascontiguousarray(values, _dt(letter))), _p(idx), base,
+                                              _sc(letter, beta))
+    return out
+
+
+def setscal(letter, y_in, first, last, base, val):
+    out = np.array(y_in, _dt(letter), copy=True)
+    getattr(orc, f"orc_{letter.lower()}setscal")(first, last, base, _sc(letter, val), _p(out))
+    return out
+
+
+def asum(letter, x):
+    out = np.zeros(1, REAL_DTYPE[letter])
+    x = np.ascontiguousarray(x, NP_DTYPE[letter])
+    getattr(orc, f"orc_{_LOW[letter]}asum")(_p(out), x.size, _p(x))
+    return out[0]
+
+
+def amax(letter, x):
+    out = np.zeros(1, REAL_DTYPE[letter])
+    x = np.ascontiguousarray(x, NP_DTYPE[letter])
+    getattr(orc, f"orc_{_LOW[letter]}amax")(_p(out), x.size, _p(x))
+    return out[0]
