@@ -50,6 +50,27 @@ void spgpuZellspmv(spgpuHandle_t handle, __device hipDoubleComplex* z, const __d
                    int avgNnzPerRow, int maxNnzPerRow, int rows, const __device hipDoubleComplex* x,
                    hipDoubleComplex beta, int baseIndex);
 
+/*
+ * ELL coefficient update ("csput"): for every i < nnz, find column aJ[i] in row aI[i] - baseIndex by
+ * binary search over the row's first rS[row] stored indices (which must ascend) and overwrite that
+ * coefficient with aVal[i]; entries that are not found, or whose row is negative, are ignored.
+ * As in the reference, aJ is compared with the STORED indices as they are (same base as rP) and
+ * `alpha` is accepted but not applied (ell_csput_base.cuh:33-75: SURVEY.md A.3 item 3).
+ * reference: ell.h:194-302, kernels/ell_csput_base.cuh:33-125.
+ */
+void spgpuSellcsput(spgpuHandle_t handle, float alpha, __device float* cM, __device const int* rP, int cMPitch,
+                    int rPPitch, __device const int* rS, int nnz, __device int* aI, __device int* aJ,
+                    __device float* aVal, int baseIndex);
+void spgpuDellcsput(spgpuHandle_t handle, double alpha, __device double* cM, __device const int* rP, int cMPitch,
+                    int rPPitch, __device const int* rS, int nnz, __device int* aI, __device int* aJ,
+                    __device double* aVal, int baseIndex);
+void spgpuCellcsput(spgpuHandle_t handle, hipFloatComplex alpha, __device hipFloatComplex* cM, __device const int* rP,
+                    int cMPitch, int rPPitch, __device const int* rS, int nnz, __device int* aI, __device int* aJ,
+                    __device hipFloatComplex* aVal, int baseIndex);
+void spgpuZellcsput(spgpuHandle_t handle, hipDoubleComplex alpha, __device hipDoubleComplex* cM, __device const int* rP,
+                    int cMPitch, int rPPitch, __device const int* rS, int nnz, __device int* aI, __device int* aJ,
+                    __device hipDoubleComplex* aVal, int baseIndex);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,15 @@ void cooToEll(void* ellValues, int* ellIndices, int ellValuesPitch, int ellIndic
               const int* cooRowIndices, const int* cooColsIndices, const void* cooValues,
               int cooBaseIndex, spgpuType_t valuesType);
 
+/* reference: ell_conv.h:64-76 / ell.c:161-202 (+ its merge sort :85-157).  ELL -> "ordered ELL":
+ * rows sorted by DESCENDING length; rows of equal length come out in DESCENDING original index
+ * (that is what the reference's merge, which takes the right run on ties, produces for every
+ * input size except rowsCount == 2, which the reference leaves unsorted -- reproduced).  rIdx[i] = original row stored at position i, dstRs[i] its length; only real
+ * entries are copied (callers zero the destination first).  Pass rIdx to spgpu?ellspmv. */
+void ellToOell(int* rIdx, void* dstEllValues, int* dstEllIndices, int* dstRs, const void* srcEllValues,
+               const int* srcEllIndices, const int* srcRs, int ellValuesPitch, int ellIndicesPitch, int rowsCount,
+               spgpuType_t valuesType);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,9 +1,9 @@
 #pragma once
 /*
- * Host-side COO -> HDIA conversion (CPU, single thread, like the reference).
- * Replaces the COO entry points of hdia_conv.h:20,45-70 / hdia.cpp:8-11,
- * 161-349 of the reference, bit for bit.  The DIA -> HDIA and blocked
- * (BCOO/BHDIA) converters of that header are a later scope row.
+ * Host-side COO -> HDIA and DIA -> HDIA conversion (CPU, single thread, like
+ * the reference).  Replaces hdia_conv.h:20-70 / hdia.cpp:8-349 of the
+ * reference, bit for bit.  The blocked (BCOO/BHDIA) converter of that header
+ * has no consumer on the path and is not provided.
  * All pointers are HOST pointers.
  */
 #include "core.h"
@@ -14,6 +14,17 @@ extern "C" {
 
 /* reference: hdia_conv.h:20 / hdia.cpp:8-11.  ceil(rowsCount/hackSize). */
 int getHdiaHacksCount(int hackSize, int rowsCount);
+
+/* reference: hdia_conv.h:22-30 / hdia.cpp:13-57.  DIA -> HDIA, pass 1: a DIA diagonal is kept in a
+ * hack iff any BYTE of its values in the hack's rows is non-zero; hackOffsets gets hacks+1 entries. */
+void computeHdiaHackOffsets(int* allocationHeight, int* hackOffsets, int hackSize, const void* diaValues,
+                            int diaValuesPitch, int diagonals, int rowsCount, spgpuType_t valuesType);
+
+/* reference: hdia_conv.h:32-43 / hdia.cpp:59-153.  DIA -> HDIA, pass 2: kept diagonals in DIA order,
+ * hdiaOffsets = their DIA offsets, values copied for the hack's existing rows (rows past rowsCount in
+ * the last hack stay untouched). */
+void diaToHdia(void* hdiaValues, int* hdiaOffsets, const int* hackOffsets, int hackSize, const void* diaValues,
+               const int* diaOffsets, int diaValuesPitch, int diagonals, int rowsCount, spgpuType_t valuesType);
 
 /* reference: hdia_conv.h:45-55 / hdia.cpp:161-228.
  * hackOffsets gets hacks+1 entries: running count of distinct diagonals per

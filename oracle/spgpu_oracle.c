@@ -302,6 +302,155 @@ void orc_cooToHdia(void* hdiaVals, int* hdiaOffsets, const int* hackOffsets, int
 }
 
 /* ======================================================================== */
+/* COO -> DIA: dia.c:5-104                                                   */
+/* ======================================================================== */
+int orc_computeDiaAllocPitch(int rows)
+{
+    return ((rows + 31) / 32) * 32;
+}
+
+/* dia.c:11-39: count distinct diagPos = rows - 1 + col - row */
+int orc_computeDiaDiagonalsCount(int rows, int cols, int nnz, const int* cooRows, const int* cooCols)
+{
+    const int span = rows + cols - 1;
+    int* id = (int*)malloc((span > 0 ? (size_t)span : 1) * sizeof(int));
+    int count = 0;
+    for (int i = 0; i < span; ++i)
+        id[i] = -1;
+    for (int e = 0; e < nnz; ++e) {
+        const int pos = rows - 1 + cooCols[e] - cooRows[e];
+        if (id[pos] < 0)
+            id[pos] = count++;
+    }
+    free(id);
+    return count;
+}
+
+/* dia.c:41-104: present diagonals numbered in ascending diagPos, offsets = diagPos - rows + 1,
+ * value to values[(row - base) + position*pitch]. */
+void orc_coo2dia(void* values, int* offsets, int pitch, int diagonals, int rows, int cols, int nnz, const int* cooRows,
+                 const int* cooCols, const void* cooVals, int base, int type)
+{
+    (void)diagonals;
+    const size_t es = orc_sizeOf(type);
+    const int span = rows + cols - 1;
+    int* toPos = (int*)malloc((span > 0 ? (size_t)span : 1) * sizeof(int));
+    int count = 0;
+    for (int i = 0; i < span; ++i)
+        toPos[i] = -1;
+    for (int e = 0; e < nnz; ++e)
+        toPos[rows - 1 + cooCols[e] - cooRows[e]] = 1;
+    for (int i = 0; i < span; ++i)
+        if (toPos[i] == 1) {
+            toPos[i] = count;
+            offsets[count++] = i - rows + 1;
+        }
+    for (int e = 0; e < nnz; ++e) {
+        const int pos = toPos[rows - 1 + cooCols[e] - cooRows[e]];
+        memcpy((char*)values + ((size_t)(cooRows[e] - base) + (size_t)pos * (size_t)pitch) * es,
+               (const char*)cooVals + (size_t)e * es, es);
+    }
+    free(toPos);
+}
+
+/* hdia.cpp:13-57 / 59-153: DIA -> HDIA; a diagonal is kept in a hack iff any byte of its values in the
+ * hack's rows is non-zero. */
+static int orc_diagInHack(const char* dia, size_t es, int d, int pitch, int hack, int hackSize, int rows)
+{
+    for (int r = 0; r < hackSize; ++r) {
+        const int row = hack * hackSize + r;
+        if (row >= rows)
+            break;
+        const char* v = dia + es * ((size_t)row + (size_t)d * (size_t)pitch);
+        for (size_t s = 0; s < es; ++s)
+            if (v[s] != 0)
+                return 1;
+    }
+    return 0;
+}
+
+void orc_computeHdiaHackOffsets(int* height, int* hackOffsets, int hackSize, const void* diaValues, int pitch,
+                                int diagonals, int rows, int type)
+{
+    const size_t es = orc_sizeOf(type);
+    const int hacks = orc_getHdiaHacksCount(hackSize, rows);
+    int total = 0;
+    hackOffsets[0] = 0;
+    for (int h = 0; h < hacks; ++h) {
+        for (int d = 0; d < diagonals; ++d)
+            total += orc_diagInHack((const char*)diaValues, es, d, pitch, h, hackSize, rows);
+        hackOffsets[h + 1] = total;
+    }
+    *height = hackOffsets[hacks];
+}
+
+void orc_diaToHdia(void* hdiaValues, int* hdiaOffsets, const int* hackOffsets, int hackSize, const void* diaValues,
+                   const int* diaOffsets, int pitch, int diagonals, int rows, int type)
+{
+    const size_t es = orc_sizeOf(type);
+    const int hacks = orc_getHdiaHacksCount(hackSize, rows);
+    for (int h = 0; h < hacks; ++h) {
+        int pos = hackOffsets[h];
+        for (int d = 0; d < diagonals; ++d) {
+            if (!orc_diagInHack((const char*)diaValues, es, d, pitch, h, hackSize, rows))
+                continue;
+            hdiaOffsets[pos] = diaOffsets[d];
+            for (int r = 0; r < hackSize && h * hackSize + r < rows; ++r)
+                memcpy((char*)hdiaValues + es * ((size_t)pos * (size_t)hackSize + (size_t)r),
+                       (const char*)diaValues + es * ((size_t)(h * hackSize + r) + (size_t)d * (size_t)pitch), es);
+            ++pos;
+        }
+    }
+}
+
+/* ======================================================================== */
+/* ELL -> ordered ELL: ell.c:85-202.  A merge sort on (length, row) whose    */
+/* merge takes the right run when lengths are equal (ell.c:94-104).          */
+/* ======================================================================== */
+static void orc_oell_sort(int* len, int* idx, int* tmpLen, int* tmpIdx, int lo, int hi) /* [lo, hi) */
+{
+    if (hi - lo < 2)
+        return;
+    const int mid = lo + (hi - lo) / 2;
+    orc_oell_sort(len, idx, tmpLen, tmpIdx, lo, mid);
+    orc_oell_sort(len, idx, tmpLen, tmpIdx, mid, hi);
+    int i = lo, j = mid, k = lo;
+    while (i < mid && j < hi) {
+        if (len[i] > len[j]) { tmpLen[k] = len[i]; tmpIdx[k++] = idx[i++]; }
+        else                 { tmpLen[k] = len[j]; tmpIdx[k++] = idx[j++]; }
+    }
+    while (i < mid) { tmpLen[k] = len[i]; tmpIdx[k++] = idx[i++]; }
+    while (j < hi)  { tmpLen[k] = len[j]; tmpIdx[k++] = idx[j++]; }
+    for (k = lo; k < hi; ++k) { len[k] = tmpLen[k]; idx[k] = tmpIdx[k]; }
+}
+
+void orc_ellToOell(int* rIdx, void* dstVals, int* dstIdx, int* dstRs, const void* srcVals, const int* srcIdx,
+                   const int* srcRs, int valPitch, int idxPitch, int rows, int type)
+{
+    const size_t es = orc_sizeOf(type);
+    int* t1 = (int*)malloc((rows > 0 ? (size_t)rows : 1) * sizeof(int));
+    int* t2 = (int*)malloc((rows > 0 ? (size_t)rows : 1) * sizeof(int));
+    for (int i = 0; i < rows; ++i) {
+        rIdx[i] = i;
+        dstRs[i] = srcRs[i];
+    }
+    /* ell.c:131-157: for exactly two rows the loop `while (n < sizetomerge*2)` and the final merge are both
+     * skipped -- two rows are left unsorted.  All other sizes sort. */
+    if (rows != 2)
+        orc_oell_sort(dstRs, rIdx, t1, t2, 0, rows);
+    free(t1);
+    free(t2);
+    for (int i = 0; i < rows; ++i) {
+        const int src = rIdx[i];
+        for (int k = 0; k < srcRs[src]; ++k) {
+            memcpy((char*)dstVals + ((size_t)i + (size_t)k * (size_t)valPitch) * es,
+                   (const char*)srcVals + ((size_t)src + (size_t)k * (size_t)valPitch) * es, es);
+            dstIdx[(size_t)i + (size_t)k * (size_t)idxPitch] = srcIdx[(size_t)src + (size_t)k * (size_t)idxPitch];
+        }
+    }
+}
+
+/* ======================================================================== */
 /* Arithmetic: hell_spmv_base.cuh:29-51 (real: (a*b)+c contracted to one fma  */
 /* by nvcc's default -fmad; complex: cuCfma / cuCmul).                        */
 /* ======================================================================== */
@@ -475,6 +624,47 @@ ORC_DEFINE_TYPE(s, float, float)
 ORC_DEFINE_TYPE(d, double, double)
 ORC_DEFINE_TYPE(c, orc_cfloat, float)
 ORC_DEFINE_TYPE(z, orc_cdouble, double)
+
+/* DIA SpMV (dia_spmv_base_template.cuh:20-216): diagonals in stored order, slot counts iff 0 <= offsets[d]+i < cols.
+ * ELL csput (ell_csput_base.cuh:33-75): binary search of aJ among the row's stored indices, overwrite on a hit;
+ * alpha unused, aJ compared with the stored index as is. */
+#define ORC_DEFINE_DIA_CSPUT(P, T)                                                                            \
+    void orc_##P##diaspmv(T* z, const T* y, T alpha, const T* dM, const int* offsets, int pitch, int rows,    \
+                          int cols, int diags, const T* x, T beta)                                            \
+    {                                                                                                         \
+        for (int i = 0; i < rows; ++i) {                                                                      \
+            T sum = P##_zero();                                                                               \
+            for (int d = 0; d < diags; ++d) {                                                                 \
+                const long long col = (long long)offsets[d] + i;                                              \
+                if (col >= 0 && col < cols)                                                                   \
+                    sum = P##_fma(dM[(size_t)i + (size_t)d * (size_t)pitch], x[col], sum);                    \
+            }                                                                                                 \
+            P##_store(z, y, i, alpha, sum, beta);                                                             \
+        }                                                                                                     \
+    }                                                                                                         \
+    void orc_##P##ellcsput(T* cM, const int* rP, int cMPitch, int rPPitch, const int* rS, int nnz,            \
+                           const int* aI, const int* aJ, const T* aVal, int baseIndex)                        \
+    {                                                                                                         \
+        for (int i = 0; i < nnz; ++i) {                                                                       \
+            const int row = aI[i] - baseIndex;                                                                \
+            if (row < 0)                                                                                      \
+                continue;                                                                                     \
+            int lower = 0, upper = rS[row] - 1;                                                               \
+            while (lower <= upper) {                                                                          \
+                const int mid = (lower + upper) / 2;                                                          \
+                const int cur = rP[(size_t)row + (size_t)mid * (size_t)rPPitch];                              \
+                if (cur == aJ[i]) {                                                                           \
+                    cM[(size_t)row + (size_t)mid * (size_t)cMPitch] = aVal[i];                                \
+                    break;                                                                                    \
+                }                                                                                             \
+                if (cur < aJ[i]) lower = mid + 1; else upper = mid - 1;                                       \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+ORC_DEFINE_DIA_CSPUT(s, float)
+ORC_DEFINE_DIA_CSPUT(d, double)
+ORC_DEFINE_DIA_CSPUT(c, orc_cfloat)
+ORC_DEFINE_DIA_CSPUT(z, orc_cdouble)
 
 /* axpby: daxpby.cu:31-45 (alpha*x + beta*y, contracted as fma(alpha, x, beta*y));
  * caxpby.cu:41-44 (fma(beta, y, alpha*x)); zaxpby.cu:42-45 (fma(alpha, x, beta*y)).

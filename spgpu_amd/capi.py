@@ -154,6 +154,19 @@ computeHdiaHackOffsetsFromCoo = _decl("computeHdiaHackOffsetsFromCoo", None,
 cooToHdia = _decl("cooToHdia", None, [ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32])
 
 
+# ---- dia.h / dia_conv.h / DIA->HDIA / OELL / csput ---------------------------------
+diaspmv, ellcsput = {}, {}
+for _L, _T in SCALAR.items():
+    diaspmv[_L] = _decl(f"spgpu{_L}diaspmv", None, [Handle, ptr, ptr, _T, ptr, ptr, i32, i32, i32, i32, ptr, _T])
+    ellcsput[_L] = _decl(f"spgpu{_L}ellcsput", None, [Handle, _T, ptr, ptr, i32, i32, ptr, i32, ptr, ptr, ptr, i32])
+computeDiaAllocPitch = _decl("computeDiaAllocPitch", i32, [i32])
+computeDiaDiagonalsCount = _decl("computeDiaDiagonalsCount", i32, [i32, i32, i32, ptr, ptr])
+coo2dia = _decl("coo2dia", None, [ptr, ptr, i32, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32])
+computeHdiaHackOffsets = _decl("computeHdiaHackOffsets", None, [C.POINTER(i32), ptr, i32, ptr, i32, i32, i32, i32])
+diaToHdia = _decl("diaToHdia", None, [ptr, ptr, ptr, i32, ptr, ptr, i32, i32, i32, i32])
+ellToOell = _decl("ellToOell", None, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32])
+
+
 def create_handle(device=0):
     h = Handle()
     status = spgpuCreate(C.byref(h), device)

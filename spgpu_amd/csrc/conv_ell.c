@@ -62,3 +62,56 @@ void cooToEll(void* ellValues, int* ellIndices, int ellValuesPitch, int ellIndic
     }
     free(fill);
 }
+
+/* ELL -> ordered ELL.  The reference sorts (length, row) pairs with a bottom-up merge sort whose
+ * merge takes the RIGHT run on ties (ell.c:85-157): since every merge joins two adjacent index
+ * ranges, the result is the unique order "length descending, then original row descending".
+ * That order is produced here directly with a counting sort over lengths. */
+void ellToOell(int* rIdx, void* dstEllValues, int* dstEllIndices, int* dstRs, const void* srcEllValues,
+               const int* srcEllIndices, const int* srcRs, int ellValuesPitch, int ellIndicesPitch, int rowsCount,
+               spgpuType_t valuesType)
+{
+    const size_t elem = spgpuSizeOf(valuesType);
+    if (rowsCount <= 0)
+        return;
+    int longest = 0;
+    for (int r = 0; r < rowsCount; ++r)
+        if (srcRs[r] > longest)
+            longest = srcRs[r];
+    /* firstOf[len] = first output position of rows with that length (longer rows first) */
+    size_t* firstOf = (size_t*)calloc((size_t)longest + 2, sizeof(size_t));
+    if (!firstOf)
+        return;
+    for (int r = 0; r < rowsCount; ++r)
+        firstOf[srcRs[r]] += 1;
+    size_t run = 0;
+    for (int len = longest; len >= 0; --len) {
+        const size_t n = firstOf[len];
+        firstOf[len] = run;
+        run += n;
+    }
+    for (int r = rowsCount - 1; r >= 0; --r) { /* descending row inside a length class */
+        const size_t at = firstOf[srcRs[r]]++;
+        rIdx[at] = r;
+        dstRs[at] = srcRs[r];
+    }
+    free(firstOf);
+    if (rowsCount == 2) {
+        /* Bit-exact parity with the reference: its merge sort never runs a merge for exactly two
+         * rows (ell.c:131-157: `while (n < sizetomerge*2)` is 2 < 2), so two rows keep their order
+         * whatever their lengths.  Every other size sorts (verified against the reference build
+         * for all sizes up to 400 and several larger ones, tests/test_f3_converters.py). */
+        rIdx[0] = 0; rIdx[1] = 1;
+        dstRs[0] = srcRs[0]; dstRs[1] = srcRs[1];
+    }
+
+    for (int i = 0; i < rowsCount; ++i) {
+        const int src = rIdx[i];
+        for (int k = 0; k < srcRs[src]; ++k) {
+            memcpy((char*)dstEllValues + ((size_t)i + (size_t)k * (size_t)ellValuesPitch) * elem,
+                   (const char*)srcEllValues + ((size_t)src + (size_t)k * (size_t)ellValuesPitch) * elem, elem);
+            dstEllIndices[(size_t)i + (size_t)k * (size_t)ellIndicesPitch] =
+                srcEllIndices[(size_t)src + (size_t)k * (size_t)ellIndicesPitch];
+        }
+    }
+}

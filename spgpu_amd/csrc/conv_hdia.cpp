@@ -107,3 +107,60 @@ extern "C" void cooToHdia(void* hdiaValues, int* hdiaOffsets, const int* hackOff
         }
     }
 }
+
+/* ---- DIA -> HDIA (reference: hdia.cpp:13-153) ----------------------------------------------- */
+namespace {
+
+/* A DIA diagonal belongs to a hack iff any byte of its values in the hack's rows is non-zero. */
+bool diagonalTouchesHack(const char* diaValues, size_t elem, int diagonal, int pitch, int firstRow, int endRow)
+{
+    const char* p = diaValues + ((size_t)diagonal * (size_t)pitch + (size_t)firstRow) * elem;
+    const char* end = p + (size_t)(endRow - firstRow) * elem;
+    for (; p != end; ++p)
+        if (*p != 0)
+            return true;
+    return false;
+}
+
+} // namespace
+
+extern "C" void computeHdiaHackOffsets(int* allocationHeight, int* hackOffsets, int hackSize, const void* diaValues,
+                                       int diaValuesPitch, int diagonals, int rowsCount, spgpuType_t valuesType)
+{
+    const size_t elem = spgpuSizeOf(valuesType);
+    const int hacks = getHdiaHacksCount(hackSize, rowsCount);
+    const char* vals = static_cast<const char*>(diaValues);
+    hackOffsets[0] = 0;
+    for (int h = 0; h < hacks; ++h) {
+        const int first = h * hackSize;
+        const int end = first + hackSize < rowsCount ? first + hackSize : rowsCount;
+        int kept = 0;
+        for (int d = 0; d < diagonals; ++d)
+            kept += diagonalTouchesHack(vals, elem, d, diaValuesPitch, first, end) ? 1 : 0;
+        hackOffsets[h + 1] = hackOffsets[h] + kept;
+    }
+    *allocationHeight = hackOffsets[hacks];
+}
+
+extern "C" void diaToHdia(void* hdiaValues, int* hdiaOffsets, const int* hackOffsets, int hackSize,
+                          const void* diaValues, const int* diaOffsets, int diaValuesPitch, int diagonals,
+                          int rowsCount, spgpuType_t valuesType)
+{
+    const size_t elem = spgpuSizeOf(valuesType);
+    const int hacks = getHdiaHacksCount(hackSize, rowsCount);
+    const char* vals = static_cast<const char*>(diaValues);
+    char* out = static_cast<char*>(hdiaValues);
+    for (int h = 0; h < hacks; ++h) {
+        const int first = h * hackSize;
+        const int end = first + hackSize < rowsCount ? first + hackSize : rowsCount;
+        size_t slot = (size_t)hackOffsets[h];
+        for (int d = 0; d < diagonals; ++d) {
+            if (!diagonalTouchesHack(vals, elem, d, diaValuesPitch, first, end))
+                continue;
+            hdiaOffsets[slot] = diaOffsets[d];
+            std::memcpy(out + slot * (size_t)hackSize * elem,
+                        vals + ((size_t)d * (size_t)diaValuesPitch + (size_t)first) * elem, (size_t)(end - first) * elem);
+            ++slot;
+        }
+    }
+}

@@ -380,6 +380,47 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
     spgpuDebugCheck(handle, "ellspmv");
 }
 
+/* ---- ELL coefficient update (include/spgpu/ell.h; reference ell_csput_base.cuh:33-75) ---- */
+template <typename T>
+__global__ __launch_bounds__(kBlockThreads) void ellCsputKernel(T* cM, const int* rP, long long cMPitch, long long rPPitch,
+                                                               const int* rS, int nnz, const int* aI, const int* aJ,
+                                                               const T* aVal, int baseIndex)
+{
+    const long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
+    if (i >= nnz)
+        return;
+    const int row = aI[i] - baseIndex;
+    if (row < 0)
+        return;
+    const int column = aJ[i];
+    int lower = 0, upper = rS[row] - 1;
+    while (lower <= upper) { /* the row's stored indices ascend */
+        const int mid = (lower + upper) / 2;
+        const int stored = rP[row + mid * rPPitch];
+        if (stored == column) {
+            cM[row + mid * cMPitch] = aVal[i];
+            return;
+        }
+        if (stored < column)
+            lower = mid + 1;
+        else
+            upper = mid - 1;
+    }
+}
+
+template <typename T, typename ApiT>
+static void ellCsput(spgpuHandle_t handle, ApiT* cM, const int* rP, int cMPitch, int rPPitch, const int* rS, int nnz,
+                     const int* aI, const int* aJ, const ApiT* aVal, int baseIndex)
+{
+    if (nnz <= 0)
+        return;
+    const unsigned blocks = (unsigned)(((long long)nnz + kBlockThreads - 1) / kBlockThreads);
+    hipLaunchKernelGGL((ellCsputKernel<T>), dim3(blocks), dim3(kBlockThreads), 0, handle->currentStream,
+                       reinterpret_cast<T*>(cM), rP, (long long)cMPitch, (long long)rPPitch, rS, nnz, aI, aJ,
+                       reinterpret_cast<const T*>(aVal), baseIndex);
+    spgpuDebugCheck(handle, "ellcsput");
+}
+
 } // namespace spgpu
 
 using namespace spgpu;
@@ -475,6 +516,32 @@ void spgpuZellspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleCom
     (void)avgNnzPerRow;
     ellSpmv<cdouble>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
                      baseIndex);
+}
+
+/* alpha is accepted and not applied, as in the reference (ell_csput_base.cuh:35,44,66). */
+void spgpuSellcsput(spgpuHandle_t handle, float alpha, float* cM, const int* rP, int cMPitch, int rPPitch, const int* rS,
+                    int nnz, int* aI, int* aJ, float* aVal, int baseIndex)
+{
+    (void)alpha;
+    ellCsput<float>(handle, cM, rP, cMPitch, rPPitch, rS, nnz, aI, aJ, aVal, baseIndex);
+}
+void spgpuDellcsput(spgpuHandle_t handle, double alpha, double* cM, const int* rP, int cMPitch, int rPPitch,
+                    const int* rS, int nnz, int* aI, int* aJ, double* aVal, int baseIndex)
+{
+    (void)alpha;
+    ellCsput<double>(handle, cM, rP, cMPitch, rPPitch, rS, nnz, aI, aJ, aVal, baseIndex);
+}
+void spgpuCellcsput(spgpuHandle_t handle, hipFloatComplex alpha, hipFloatComplex* cM, const int* rP, int cMPitch,
+                    int rPPitch, const int* rS, int nnz, int* aI, int* aJ, hipFloatComplex* aVal, int baseIndex)
+{
+    (void)alpha;
+    ellCsput<cfloat>(handle, cM, rP, cMPitch, rPPitch, rS, nnz, aI, aJ, aVal, baseIndex);
+}
+void spgpuZellcsput(spgpuHandle_t handle, hipDoubleComplex alpha, hipDoubleComplex* cM, const int* rP, int cMPitch,
+                    int rPPitch, const int* rS, int nnz, int* aI, int* aJ, hipDoubleComplex* aVal, int baseIndex)
+{
+    (void)alpha;
+    ellCsput<cdouble>(handle, cM, rP, cMPitch, rPPitch, rS, nnz, aI, aJ, aVal, baseIndex);
 }
 
 } // extern "C"

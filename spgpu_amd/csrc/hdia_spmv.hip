@@ -41,9 +41,10 @@ template <typename T> struct HdiaArgs {
     const T* x;
     const T* dM;
     const int* offsets;
-    const int* hackOffsets;
+    const int* hackOffsets; /* NULL: plain DIA -- one hack holding all rows, `flatDiags` diagonals */
     T alpha, beta;
     int rows, cols, hackSize;
+    int flatDiags;
     int wideIO;
     int xcdOrder; /* 0: hardware order; 1: XCD-contiguous eighths; n > 1: runs of n blocks per XCD */
 };
@@ -68,11 +69,16 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
     int firstDiag = 0, diags = 0;
     long long slab = 0;
     if (live) {
-        const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
-        const unsigned hack = r0 / hs;
-        firstDiag = a.hackOffsets[hack];
-        diags = a.hackOffsets[hack + 1] - firstDiag;
-        slab = (long long)firstDiag * hs + (r0 - hack * hs);
+        if (a.hackOffsets) {
+            const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
+            const unsigned hack = r0 / hs;
+            firstDiag = a.hackOffsets[hack];
+            diags = a.hackOffsets[hack + 1] - firstDiag;
+            slab = (long long)firstDiag * hs + (r0 - hack * hs);
+        } else { /* DIA: dM[row + d*pitch], every row sees every stored diagonal */
+            diags = a.flatDiags;
+            slab = row0;
+        }
     }
     const int waveDiags = waveMax(diags); /* wave-uniform trip count */
     const bool stripInside = row0 + RPL <= a.rows;
@@ -184,7 +190,8 @@ static void launchHdia(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
 
 template <typename T, typename ApiT>
 static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, const ApiT* dM, const int* offsets,
-                     int hackSize, const int* hackOffsets, int rows, int cols, const ApiT* x, ApiT beta)
+                     int hackSize, const int* hackOffsets, int rows, int cols, const ApiT* x, ApiT beta,
+                     int flatDiags = 0)
 {
     static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
     if (rows <= 0 || hackSize <= 0)
@@ -201,6 +208,7 @@ static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     a.rows = rows;
     a.cols = cols;
     a.hackSize = hackSize;
+    a.flatDiags = flatDiags;
 
     const char* xo = getenv("SPGPU_XCD_ORDER");
     a.xcdOrder = xo && *xo ? atoi(xo) : 0;
@@ -266,6 +274,33 @@ void spgpuZhdiaspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleCo
                     int rows, int cols, const hipDoubleComplex* x, hipDoubleComplex beta)
 {
     hdiaSpmv<cdouble>(handle, z, y, alpha, dM, offsets, hackSize, hackOffsets, rows, cols, x, beta);
+}
+
+/* ---- DIA (include/spgpu/dia.h; reference dia.h:42-143, dia_spmv_base_template.cuh:20-216): the same
+ * kernel over one all-rows hack: hackSize = dMPitch, hackOffsets = NULL. ---- */
+#include "spgpu/dia.h"
+
+void spgpuSdiaspmv(spgpuHandle_t handle, float* z, const float* y, float alpha, const float* dM, const int* offsets,
+                   int dMPitch, int rows, int cols, int diags, const float* x, float beta)
+{
+    hdiaSpmv<float>(handle, z, y, alpha, dM, offsets, dMPitch, nullptr, rows, cols, x, beta, diags);
+}
+void spgpuDdiaspmv(spgpuHandle_t handle, double* z, const double* y, double alpha, const double* dM, const int* offsets,
+                   int dMPitch, int rows, int cols, int diags, const double* x, double beta)
+{
+    hdiaSpmv<double>(handle, z, y, alpha, dM, offsets, dMPitch, nullptr, rows, cols, x, beta, diags);
+}
+void spgpuCdiaspmv(spgpuHandle_t handle, hipFloatComplex* z, const hipFloatComplex* y, hipFloatComplex alpha,
+                   const hipFloatComplex* dM, const int* offsets, int dMPitch, int rows, int cols, int diags,
+                   const hipFloatComplex* x, hipFloatComplex beta)
+{
+    hdiaSpmv<cfloat>(handle, z, y, alpha, dM, offsets, dMPitch, nullptr, rows, cols, x, beta, diags);
+}
+void spgpuZdiaspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleComplex* y, hipDoubleComplex alpha,
+                   const hipDoubleComplex* dM, const int* offsets, int dMPitch, int rows, int cols, int diags,
+                   const hipDoubleComplex* x, hipDoubleComplex beta)
+{
+    hdiaSpmv<cdouble>(handle, z, y, alpha, dM, offsets, dMPitch, nullptr, rows, cols, x, beta, diags);
 }
 
 } // extern "C"

@@ -86,6 +86,56 @@ def coo_to_hdia(n_rows, n_cols, coo_rows, coo_cols, coo_vals, hack_size=32, coo_
                 height=height.value)
 
 
+def coo_to_dia(n_rows, n_cols, coo_rows, coo_cols, coo_vals, coo_base=0):
+    """COO -> DIA as diaPerf.cpp:127-160 drives it (values zeroed first)."""
+    coo_rows, coo_cols = _i32(coo_rows), _i32(coo_cols)
+    coo_vals = np.ascontiguousarray(coo_vals)
+    letter = LETTER_OF[coo_vals.dtype]
+    nnz = int(coo_rows.size)
+    diags = capi.computeDiaDiagonalsCount(n_rows, n_cols, nnz, _p(coo_rows), _p(coo_cols))
+    pitch = capi.computeDiaAllocPitch(n_rows)
+    values = np.zeros(max(diags * pitch, 1), dtype=coo_vals.dtype)
+    offsets = np.zeros(max(diags, 1), dtype=np.int32)
+    capi.coo2dia(_p(values), _p(offsets), pitch, diags, n_rows, n_cols, nnz, _p(coo_rows), _p(coo_cols), _p(coo_vals),
+                 coo_base, capi.TYPE_CODE[letter])
+    return dict(letter=letter, rows=n_rows, cols=n_cols, values=values[:diags * pitch], offsets=offsets[:diags],
+                pitch=pitch, diags=diags)
+
+
+def dia_to_hdia(dia, hack_size=32):
+    """DIA -> HDIA as diaPerf.cpp:254-275 drives it, with hdiaValues zeroed first."""
+    n_rows = dia["rows"]
+    hacks = capi.getHdiaHacksCount(hack_size, n_rows)
+    hack_offsets = np.zeros(hacks + 1, dtype=np.int32)
+    height = C.c_int(0)
+    dv = dia["values"] if dia["values"].size else np.zeros(1, dia["values"].dtype)
+    do = dia["offsets"] if dia["offsets"].size else np.zeros(1, np.int32)
+    code = capi.TYPE_CODE[dia["letter"]]
+    capi.computeHdiaHackOffsets(C.byref(height), _p(hack_offsets), hack_size, _p(dv), dia["pitch"], dia["diags"], n_rows, code)
+    values = np.zeros(max(hack_size * height.value, 1), dtype=dia["values"].dtype)
+    offsets = np.zeros(max(height.value, 1), dtype=np.int32)
+    capi.diaToHdia(_p(values), _p(offsets), _p(hack_offsets), hack_size, _p(dv), _p(do), dia["pitch"], dia["diags"], n_rows, code)
+    return dict(letter=dia["letter"], rows=n_rows, cols=dia["cols"], values=values[:hack_size * height.value],
+                offsets=offsets[:height.value], hack_offsets=hack_offsets, hack_size=hack_size, height=height.value)
+
+
+def ell_to_oell(ell):
+    """ELL -> ordered ELL (rows by descending length) as hellPerf.cpp:319-332 drives it; returns (oell, rIdx)."""
+    n_rows = ell["rows"]
+    r_idx = np.zeros(max(n_rows, 1), dtype=np.int32)
+    dst_rs = np.zeros(max(n_rows, 1), dtype=np.int32)
+    values, indices = np.zeros_like(ell["values"]), np.zeros_like(ell["indices"])
+    ev = ell["values"] if ell["values"].size else np.zeros(1, ell["values"].dtype)
+    ei = ell["indices"] if ell["indices"].size else np.zeros(1, np.int32)
+    vv = values if values.size else np.zeros(1, ell["values"].dtype)
+    ii = indices if indices.size else np.zeros(1, np.int32)
+    rs = np.ascontiguousarray(ell["row_lengths"], dtype=np.int32)
+    capi.ellToOell(_p(r_idx), _p(vv), _p(ii), _p(dst_rs), _p(ev), _p(ei), _p(rs), ell["pitch"], ell["pitch"], n_rows,
+                   capi.TYPE_CODE[ell["letter"]])
+    out = dict(ell, values=values, indices=indices, row_lengths=dst_rs[:n_rows])
+    return out, r_idx[:n_rows]
+
+
 # ---- device residency + SpMV calls -------------------------------------------------
 
 def to_device(a, device="cuda:0"):
@@ -151,3 +201,17 @@ class DeviceHdia:
         capi.hdiaspmv[L](handle, _dp(z), _dp(y), capi.scalar(L, alpha), _dp(self.dM), _dp(self.offsets),
                          self.hack_size, _dp(self.hack_offsets), self.rows, self.cols, _dp(x),
                          capi.scalar(L, beta))
+
+
+class DeviceDia:
+    """A DIA matrix resident in HBM; ``spmv`` is one spgpu?diaspmv call."""
+
+    def __init__(self, dia, device="cuda:0"):
+        self.letter, self.rows, self.cols = dia["letter"], dia["rows"], dia["cols"]
+        self.pitch, self.diags = dia["pitch"], dia["diags"]
+        self.dM, self.offsets = to_device(dia["values"], device), to_device(dia["offsets"], device)
+
+    def spmv(self, handle, z, y, alpha, x, beta):
+        L = self.letter
+        capi.diaspmv[L](handle, _dp(z), _dp(y), capi.scalar(L, alpha), _dp(self.dM), _dp(self.offsets), self.pitch,
+                        self.rows, self.cols, self.diags, _dp(x), capi.scalar(L, beta))

@@ -60,6 +60,12 @@ _CONV_SIGS = {
     "getHdiaHacksCount": (i32, [i32, i32]),
     "computeHdiaHackOffsetsFromCoo": (None, [C.POINTER(i32), ptr, i32, i32, i32, i32, ptr, ptr, i32]),
     "cooToHdia": (None, [ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32]),
+    "computeDiaAllocPitch": (i32, [i32]),
+    "computeDiaDiagonalsCount": (i32, [i32, i32, i32, ptr, ptr]),
+    "coo2dia": (None, [ptr, ptr, i32, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32]),
+    "computeHdiaHackOffsets": (None, [C.POINTER(i32), ptr, i32, ptr, i32, i32, i32, i32]),
+    "diaToHdia": (None, [ptr, ptr, ptr, i32, ptr, ptr, i32, i32, i32, i32]),
+    "ellToOell": (None, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32]),
 }
 
 
@@ -122,6 +128,48 @@ class ConverterSet:
         return dict(letter=letter, rows=n_rows, cols=n_cols, values=values[:hack_size * height.value],
                     offsets=offsets[:height.value], hack_offsets=hack_offsets, hack_size=hack_size,
                     height=height.value)
+
+
+    def coo_to_dia(self, n_rows, n_cols, rows, cols, vals, coo_base=0):
+        rows, cols = np.ascontiguousarray(rows, np.int32), np.ascontiguousarray(cols, np.int32)
+        vals = np.ascontiguousarray(vals)
+        letter = LETTER_OF[vals.dtype]
+        diags = self.computeDiaDiagonalsCount(n_rows, n_cols, rows.size, _p(rows), _p(cols))
+        pitch = self.computeDiaAllocPitch(n_rows)
+        values = np.zeros(max(diags * pitch, 1), vals.dtype)
+        offsets = np.zeros(max(diags, 1), np.int32)
+        self.coo2dia(_p(values), _p(offsets), pitch, diags, n_rows, n_cols, rows.size, _p(rows), _p(cols), _p(vals),
+                     coo_base, TYPE_CODE[letter])
+        return dict(letter=letter, rows=n_rows, cols=n_cols, values=values[:diags * pitch], offsets=offsets[:diags],
+                    pitch=pitch, diags=diags)
+
+    def dia_to_hdia(self, dia, hack_size=32):
+        n_rows = dia["rows"]
+        hacks = self.getHdiaHacksCount(hack_size, n_rows)
+        hack_offsets = np.zeros(hacks + 1, np.int32)
+        height = i32(0)
+        dv = dia["values"] if dia["values"].size else np.zeros(1, dia["values"].dtype)
+        do = dia["offsets"] if dia["offsets"].size else np.zeros(1, np.int32)
+        code = TYPE_CODE[dia["letter"]]
+        self.computeHdiaHackOffsets(C.byref(height), _p(hack_offsets), hack_size, _p(dv), dia["pitch"], dia["diags"],
+                                    n_rows, code)
+        values = np.zeros(max(hack_size * height.value, 1), dia["values"].dtype)
+        offsets = np.zeros(max(height.value, 1), np.int32)
+        self.diaToHdia(_p(values), _p(offsets), _p(hack_offsets), hack_size, _p(dv), _p(do), dia["pitch"], dia["diags"],
+                       n_rows, code)
+        return dict(letter=dia["letter"], rows=n_rows, cols=dia["cols"], values=values[:hack_size * height.value],
+                    offsets=offsets[:height.value], hack_offsets=hack_offsets, hack_size=hack_size, height=height.value)
+
+    def ell_to_oell(self, ell):
+        n_rows = ell["rows"]
+        r_idx, dst_rs = np.zeros(max(n_rows, 1), np.int32), np.zeros(max(n_rows, 1), np.int32)
+        values, indices = np.zeros_like(ell["values"]), np.zeros_like(ell["indices"])
+        one = lambda a, dt: a if a.size else np.zeros(1, dt)
+        rs = np.ascontiguousarray(ell["row_lengths"], np.int32)
+        self.ellToOell(_p(r_idx), _p(one(values, ell["values"].dtype)), _p(one(indices, np.int32)), _p(dst_rs),
+                       _p(one(ell["values"], ell["values"].dtype)), _p(one(ell["indices"], np.int32)), _p(one(rs, np.int32)),
+                       ell["pitch"], ell["pitch"], n_rows, TYPE_CODE[ell["letter"]])
+        return dict(ell, values=values, indices=indices, row_lengths=dst_rs[:n_rows]), r_idx[:n_rows]
 
 
 def _resolve_oracle(name, res, args):
@@ -325,3 +373,32 @@ def amax(letter, x):
     x = np.ascontiguousarray(x, NP_DTYPE[letter])
     getattr(orc, f"orc_{_LOW[letter]}amax")(_p(out), x.size, _p(x))
     return out[0]
+
+
+for _L, _T in SCALAR.items():
+    _l = _LOW[_L]
+    _f = getattr(orc, f"orc_{_l}diaspmv")
+    _f.restype, _f.argtypes = None, [ptr, ptr, _T, ptr, ptr, i32, i32, i32, i32, ptr, _T]
+    _f = getattr(orc, f"orc_{_l}ellcsput")
+    _f.restype, _f.argtypes = None, [ptr, ptr, i32, i32, ptr, i32, ptr, ptr, ptr, i32]
+
+
+def dia_spmv(dia, x, y, alpha, beta):
+    L = dia["letter"]
+    z = np.zeros(dia["rows"], NP_DTYPE[L]) if y is None else np.array(y, NP_DTYPE[L], copy=True)
+    yy = None if y is None else np.ascontiguousarray(y, NP_DTYPE[L])
+    getattr(orc, f"orc_{_LOW[L]}diaspmv")(_p(z), _p(yy), scalar(L, alpha), _p(dia["values"]), _p(dia["offsets"]), dia["pitch"],
+                                          dia["rows"], dia["cols"], dia["diags"], _p(np.ascontiguousarray(x, NP_DTYPE[L])),
+                                          scalar(L, beta))
+    return z
+
+
+def ell_csput(ell, a_i, a_j, a_val, base):
+    """Returns the updated ELL value array."""
+    L = ell["letter"]
+    out = np.array(ell["values"], copy=True)
+    ai, aj = np.ascontiguousarray(a_i, np.int32), np.ascontiguousarray(a_j, np.int32)
+    av = np.ascontiguousarray(a_val, NP_DTYPE[L])
+    getattr(orc, f"orc_{_LOW[L]}ellcsput")(_p(out), _p(ell["indices"]), ell["pitch"], ell["pitch"], _p(ell["row_lengths"]),
+                                           ai.size, _p(ai), _p(aj), _p(av), base)
+    return out
