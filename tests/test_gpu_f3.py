@@ -28,16 +28,17 @@ def test_dia_spmv(gpu, letter):
         dia = formats.coo_to_dia(n, m, r, c, v)
         x, y = synth.values_for(letter, 4, m), synth.values_for(letter, 5, n)
         mat = formats.DeviceDia(dia)
+        dx, dy = formats.to_device(x), formats.to_device(y)   # keep device buffers alive across the async calls
         for alpha, beta in ((1.0, 0.0), (0.5, -1.5)):
-            dz = torch.full((n,), float("nan"), dtype=formats.to_device(y).dtype, device="cuda:0")
-            mat.spmv(gpu, dz, formats.to_device(y), alpha, formats.to_device(x), beta)
+            dz = torch.full((n,), float("nan"), dtype=dy.dtype, device="cuda:0")
+            mat.spmv(gpu, dz, dy, alpha, dx, beta)
             torch.cuda.synchronize()
             want = O.dia_spmv(dia, x, y if beta else None, alpha, beta)
             assert dz.cpu().numpy().tobytes() == want.tobytes()
         # the same matrix through DIA -> HDIA gives the same bits
         hd = formats.dia_to_hdia(dia, 32)
         dz2 = torch.empty_like(dz)
-        formats.DeviceHdia(hd).spmv(gpu, dz2, None, 1.0, formats.to_device(x), 0.0)
+        formats.DeviceHdia(hd).spmv(gpu, dz2, None, 1.0, dx, 0.0)
         torch.cuda.synchronize()
         assert dz2.cpu().numpy().tobytes() == O.dia_spmv(dia, x, None, 1.0, 0.0).tobytes()
 
@@ -55,8 +56,9 @@ def test_ell_csput(gpu, letter):
     a_j[1::40] = n + 5                 # column not stored: ignored
     a_val = synth.values_for(letter, 6, 300)
     mat = formats.DeviceEll(ell)
+    d_i, d_j, d_val = formats.to_device(a_i), formats.to_device(a_j), formats.to_device(a_val)   # alive until the sync
     capi.ellcsput[letter](gpu, capi.scalar(letter, 3.0), _p(mat.cM), _p(mat.rP), mat.pitch, mat.pitch, _p(mat.rS), 300,
-                          _p(formats.to_device(a_i)), _p(formats.to_device(a_j)), _p(formats.to_device(a_val)), 1)
+                          _p(d_i), _p(d_j), _p(d_val), 1)
     torch.cuda.synchronize()
     assert mat.cM.cpu().numpy().tobytes() == O.ell_csput(ell, a_i, a_j, a_val, 1).tobytes()
 
