@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--spmm-rows-per-gpu", type=int, default=5_000_000)
     p.add_argument("--rhs", type=int, default=16)
     p.add_argument("--spmm-pattern", default="banded", choices=["banded", "random", "window"])
+    p.add_argument("--force-split", action="store_true", help="spmm: cut by column ownership even on one rank (rehearsal)")
     p.add_argument("--no-split", action="store_true",
                    help="spmm: do not cut the local block by column ownership (no compute/all-gather overlap)")
     return p.parse_args()
@@ -86,7 +87,7 @@ def time_launches(stream, fn, steps):
     return start.elapsed_time(stop) * 1e-3
 
 
-def spot_check_hell(h, x, y, z, alpha, beta, phases=1, rows_per_probe=2048):
+def spot_check_hell(h, x, y, z, alpha, beta, rows_per_probe=2048):
     """Parity at full size: three hack-aligned row windows of the device result against the oracle."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -97,7 +98,7 @@ def spot_check_hell(h, x, y, z, alpha, beta, phases=1, rows_per_probe=2048):
     for first in (0, (n // 2) // h["hack_size"] * h["hack_size"], n - rows_per_probe):
         sub = synth.hell_rows_to_host(h, first, rows_per_probe)
         ys = y[first:first + rows_per_probe].cpu().numpy() if beta != 0 else None
-        want = O.hell_spmv(sub, xs, ys, alpha, beta, phases=phases)
+        want = O.default_spmv(sub, xs, ys, alpha, beta)
         got = z[first:first + rows_per_probe].cpu().numpy()
         if got.tobytes() != want.tobytes():
             return f"MISMATCH in rows [{first},{first + rows_per_probe})"
@@ -278,7 +279,7 @@ def run_spmm(args, rank, world):
     blocks = [(r * rows_local, rows_local) for r in range(world)]
     block = synth.hell_uniform_on_device(rows_local, L, args.spmm_pattern, "D", 32, seed=11 + rank, device=dev,
                                          n_cols=n_total, row_offset=first)
-    split = world > 1 and not args.no_split
+    split = (world > 1 or args.force_split) and not args.no_split
     if split:
         own, rest = synth.split_uniform_hell_by_columns(block, first, rows_local)
         del block
@@ -393,17 +394,23 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world > 1:
+    # SPGPU_BENCH_FORCE_DIST=1: initialise RCCL and run the collectives even with one rank (rehearsal of the
+    # multi-GPU code path on a 1-GPU box)
+    force_dist = os.environ.get("SPGPU_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         dist.init_process_group("nccl")
     workload = args.workload if args.workload != "auto" else ("spmv" if world == 1 else "spmm")
     try:
         (run_spmv if workload == "spmv" else run_spmm)(args, rank, world)
     finally:
-        if world > 1:
+        if world > 1 or force_dist:
             import torch.distributed as dist
             dist.destroy_process_group()
 

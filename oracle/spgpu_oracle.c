@@ -506,7 +506,7 @@ static inline double d_abs2acc(double v, double acc) { return fma(v, v, acc); }
 static inline float c_abs2acc(orc_cfloat v, float acc) { return fmaf(v.y, v.y, fmaf(v.x, v.x, acc)); }
 static inline double z_abs2acc(orc_cdouble v, double acc) { return fma(v.y, v.y, fma(v.x, v.x, acc)); }
 
-#define ORC_MAX_PHASES 8
+#define ORC_MAX_PHASES 64
 
 /*
  * One body for the four value types.
@@ -624,6 +624,67 @@ ORC_DEFINE_TYPE(s, float, float)
 ORC_DEFINE_TYPE(d, double, double)
 ORC_DEFINE_TYPE(c, orc_cfloat, float)
 ORC_DEFINE_TYPE(z, orc_cdouble, double)
+
+/* The MI355X slab kernel's "tail" order (spgpu_amd/csrc/ellpack_spmv.hip, TAIL): a wavefront owns
+ * groupRows consecutive rows, rowsPerLane per lane.  It walks slab columns `step` at a time while more than
+ * tailLanes lanes still have entries; the first column block at which <= tailLanes lanes are busy is
+ * tailFrom.  A row's sum is then  (entries k < tailFrom in ascending k)  +  (entries k >= tailFrom split
+ * over 64 partial sums by (k - tailFrom) mod 64, each ascending, combined pairwise p with p^1, p^2, ... p^32).
+ * Same arithmetic and epilogue as orc_?hellspmv / orc_?ellspmv; hackOffsets == NULL selects ELL addressing. */
+#define ORC_DEFINE_TAIL(P, T)                                                                                 \
+    void orc_##P##spmv_tail(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
+                            const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \
+                            const int* rIdx, int rows, const T* x, T beta, int baseIndex, int groupRows,      \
+                            int rowsPerLane, int step, int tailLanes)                                         \
+    {                                                                                                         \
+        for (int g0 = 0; g0 < rows; g0 += groupRows) {                                                        \
+            const int gEnd = g0 + groupRows < rows ? g0 + groupRows : rows;                                   \
+            int longest = 0;                                                                                  \
+            for (int i = g0; i < gEnd; ++i) {                                                                 \
+                const int l = rS ? rS[i] : maxNnz;                                                            \
+                if (l > longest) longest = l;                                                                 \
+            }                                                                                                 \
+            int tailFrom = longest;                                                                           \
+            for (int kBase = 0; kBase < longest; kBase += step) {                                             \
+                int busy = 0;                                                                                 \
+                for (int s0 = g0; s0 < gEnd; s0 += rowsPerLane) {                                             \
+                    int laneLongest = 0;                                                                      \
+                    for (int i = s0; i < s0 + rowsPerLane && i < gEnd; ++i) {                                 \
+                        const int l = rS ? rS[i] : maxNnz;                                                    \
+                        if (l > laneLongest) laneLongest = l;                                                 \
+                    }                                                                                         \
+                    busy += kBase < laneLongest;                                                              \
+                }                                                                                             \
+                if (busy <= tailLanes) { tailFrom = kBase; break; }                                           \
+            }                                                                                                 \
+            for (int i = g0; i < gEnd; ++i) {                                                                 \
+                const int len = rS ? rS[i] : maxNnz;                                                          \
+                const size_t slot0 = hackOffsets ? (size_t)hackOffsets[i / hackSize] + (size_t)(i % hackSize) : (size_t)i; \
+                const size_t vs = hackOffsets ? (size_t)hackSize : (size_t)cMPitch;                           \
+                const size_t is = hackOffsets ? (size_t)hackSize : (size_t)rPPitch;                           \
+                T sum = P##_zero();                                                                           \
+                for (int k = 0; k < len && k < tailFrom; ++k) {                                               \
+                    const int col = rP[slot0 + (size_t)k * is] - baseIndex;                                   \
+                    if (col >= 0) sum = P##_fma(cM[slot0 + (size_t)k * vs], x[col], sum);                     \
+                }                                                                                             \
+                if (len > tailFrom) {                                                                         \
+                    T part[ORC_MAX_PHASES];                                                                   \
+                    for (int p = 0; p < 64; ++p) part[p] = P##_zero();                                        \
+                    for (int k = tailFrom; k < len; ++k) {                                                    \
+                        const int col = rP[slot0 + (size_t)k * is] - baseIndex;                               \
+                        if (col >= 0)                                                                         \
+                            part[(k - tailFrom) % 64] = P##_fma(cM[slot0 + (size_t)k * vs], x[col], part[(k - tailFrom) % 64]); \
+                    }                                                                                         \
+                    sum = P##_add(sum, P##_combine(part, 64));                                                \
+                }                                                                                             \
+                P##_store(z, y, rIdx ? rIdx[i] : i, alpha, sum, beta);                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+ORC_DEFINE_TAIL(s, float)
+ORC_DEFINE_TAIL(d, double)
+ORC_DEFINE_TAIL(c, orc_cfloat)
+ORC_DEFINE_TAIL(z, orc_cdouble)
 
 /* DIA SpMV (dia_spmv_base_template.cuh:20-216): diagonals in stored order, slot counts iff 0 <= offsets[d]+i < cols.
  * ELL csput (ell_csput_base.cuh:33-75): binary search of aJ among the row's stored indices, overwrite on a hit;

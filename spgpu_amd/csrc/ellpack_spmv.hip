@@ -68,10 +68,13 @@ template <typename T> struct SlabArgs {
     int maxNnz;   /* ELL without rS */
     long long valStride, idxStride; /* elements between two slab columns */
     int wideIO;   /* y and z are aligned for RPL-wide access */
+    int tailLanes; /* TAIL kernels: switch to whole-wave rows when <= this many lanes are busy */
 };
 
 constexpr int kBlockThreads = 256;
 constexpr int kWavesPerBlock = kBlockThreads / kWave;
+constexpr int kTailLanes = 8;  /* switch to whole-wave row processing when <= this many lanes are busy */
+constexpr int kTailUnroll = 4; /* entries per lane in flight in tail mode */
 
 /*
  * RPL    rows per lane (1, or 16/sizeof(T) with 16-byte loads)
@@ -80,7 +83,7 @@ constexpr int kWavesPerBlock = kBlockThreads / kWave;
  * UNROLL slab-column loads issued back to back before the first gather
  * One wavefront owns 64/PH strips = (64/PH)*RPL consecutive rows.
  */
-template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, bool PIPE>
+template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, bool PIPE, bool TAIL>
 __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
@@ -175,19 +178,80 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
     };
 
     constexpr int STEP = PH * UNROLL;
+    /* TAIL (PH == 1 only): when at most kTailLanes lanes of the wavefront still have entries left, the
+     * slab loop would run on with >= 7/8 of its lanes idle (ragged matrices: one long row keeps a whole
+     * group looping).  The loop stops there and the few remaining rows are finished one at a time by the
+     * WHOLE wavefront: lane l takes entries tailFrom + l, + 64, ...; the 64 partial sums are combined
+     * with lane-xor shuffles and added to the owner lane's running sum. */
+    int tailFrom = groupLongest;
+    auto switchToTail = [&](int kBase) -> bool {
+        if constexpr (TAIL) {
+            if (__popcll(__ballot(kBase < laneLongest)) <= a.tailLanes) {
+                tailFrom = kBase;
+                return true;
+            }
+        }
+        return false;
+    };
     if constexpr (PIPE) {
         Stage cur, nxt;
         fetch(0, cur);
         for (int kBase = 0; kBase < groupLongest; kBase += STEP) {
+            if (switchToTail(kBase))
+                break;
             fetch(kBase + STEP, nxt); /* lanes past their rows' end fetch nothing */
             consume(kBase, cur);
             cur = nxt;
         }
     } else {
         for (int kBase = 0; kBase < groupLongest; kBase += STEP) {
+            if (switchToTail(kBase))
+                break;
             Stage cur;
             fetch(kBase, cur);
             consume(kBase, cur);
+        }
+    }
+
+    if constexpr (TAIL) {
+        static_assert(!TAIL || PH == 1, "tail mode is written for one phase");
+        unsigned long long pending = __ballot(tailFrom < laneLongest);
+        while (pending) { /* wave-uniform */
+            const int owner = __ffsll((long long)pending) - 1;
+            pending &= pending - 1;
+            const long long ownerSlab = __shfl(slab, owner, kWave);
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                const int rowLen = __shfl(len[t], owner, kWave);
+                if (rowLen <= tailFrom)
+                    continue;
+                const T* __restrict__ rowVals = a.cM + ownerSlab + t;
+                const int* __restrict__ rowIdxs = a.rP + ownerSlab + t;
+                T part = zeroOf<T>();
+                for (int k0 = tailFrom + lane; k0 < rowLen + (kTailUnroll - 1) * kWave; k0 += kTailUnroll * kWave) {
+                    T tv[kTailUnroll];
+                    int tc[kTailUnroll];
+#pragma unroll
+                    for (int u = 0; u < kTailUnroll; ++u) {
+                        const int k = k0 + u * kWave;
+                        const bool in = k < rowLen;
+                        tv[u] = in ? rowVals[(long long)k * a.valStride] : zeroOf<T>();
+                        tc[u] = in ? rowIdxs[(long long)k * a.idxStride] - a.baseIndex : -1;
+                    }
+                    T tx[kTailUnroll];
+#pragma unroll
+                    for (int u = 0; u < kTailUnroll; ++u)
+                        tx[u] = x[tc[u] >= 0 ? tc[u] : 0];
+#pragma unroll
+                    for (int u = 0; u < kTailUnroll; ++u)
+                        part = pick(tc[u] >= 0, mulAdd(tv[u], tx[u], part), part);
+                }
+#pragma unroll
+                for (int m = 1; m < kWave; m <<= 1)
+                    part = add(part, laneXor(part, m));
+                if (lane == owner)
+                    sum[t] = add(sum[t], part);
+            }
         }
     }
 
@@ -242,17 +306,17 @@ static bool alignedTo(const void* p, size_t bytes)
     return ((uintptr_t)p % bytes) == 0;
 }
 
-template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool PIPE = false>
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool PIPE = false, bool TAIL = false>
 static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
 {
     constexpr int GROUP_ROWS = (kWave / PH) * RPL;
     const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
     const unsigned blocks = (unsigned)((groups + kWavesPerBlock - 1) / kWavesPerBlock);
     if (nt)
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE>), dim3(blocks),
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE, TAIL>), dim3(blocks),
                            dim3(kBlockThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE>), dim3(blocks),
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE, TAIL>), dim3(blocks),
                            dim3(kBlockThreads), 0, stream, a);
 }
 
@@ -280,14 +344,16 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
      * (5.44 TB/s); 16-byte elements (Z) and unaligned streams take RPL = 1 with 2 phases x 4
      * columns, prefetched (5.93 TB/s).
      * SPGPU_SPMV_VARIANT (experiments; 0 = this table):
-     *   1 wide PHx2 | 2 wide 1x4 | 3 narrow 2x4 | 4 narrow 1x4 | 6 wide PHx2 pipe | 12 wide 1x8 pipe | 13 narrow 2x4 pipe
+     *   1 wide PHx2 | 2 wide 1x4 | 3 narrow 2x4 | 4 narrow 1x4 | 6 wide PHx2 pipe | 12 wide 1x8 pipe |
+     *   13 narrow 2x4 pipe | 17 wide 1x8 pipe + whole-wave tail rows
      *   (5,7..11,14..16 exist only in -DSPGPU_TUNING_VARIANTS builds)
      * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams (default 1). */
+    a.tailLanes = envInt("SPGPU_TAIL_LANES", kTailLanes);
     int variant = envInt("SPGPU_SPMV_VARIANT", 0);
     const bool nt = envInt("SPGPU_NT_LOADS", 1) != 0;
-    if (variant < 1 || variant > 16)
-        variant = !wideOk ? 13 : (sizeof(T) == 4 ? 6 : 12);
-    const bool narrowVariant = variant == 3 || variant == 4 || variant >= 13;
+    if (variant < 1 || variant > 17)
+        variant = !wideOk ? 13 : (sizeof(T) == 4 ? 6 : 17);
+    const bool narrowVariant = variant == 3 || variant == 4 || (variant >= 13 && variant <= 16);
     if (!wideOk && !narrowVariant)
         variant = 13;
 
@@ -306,7 +372,8 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 10: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 1, true>(stream, a, nt); break;
             case 11: launchSlab<T, WIDE, 1, IS_HELL, 2, true>(stream, a, nt); break;
 #endif
-            default: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break; /* 12 */
+            case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
+            default: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true>(stream, a, nt); break; /* 17 */
             }
             return;
         }

@@ -80,7 +80,7 @@ class ShardedSpmm:
 
     def gather_x(self, x_local, async_op=False):
         """All-gather of the X row blocks into x_full (rows in rank order)."""
-        if self.world == 1:
+        if self.world == 1 and not (self.dist.is_available() and self.dist.is_initialized()):
             self.x_full[: x_local.shape[0]].copy_(x_local)
             return None
         if self.equal_blocks:

@@ -402,3 +402,40 @@ def ell_csput(ell, a_i, a_j, a_val, base):
     getattr(orc, f"orc_{_LOW[L]}ellcsput")(_p(out), _p(ell["indices"]), ell["pitch"], ell["pitch"], _p(ell["row_lengths"]),
                                            ai.size, _p(ai), _p(aj), _p(av), base)
     return out
+
+
+# ---- the slab kernel's tail-mode summation order (default fp64 / complex-fp32 kernel) ----------
+TAIL_SHAPE = {"D": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=8),
+              "C": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=8)}
+for _L, _T in SCALAR.items():
+    _f = getattr(orc, f"orc_{_LOW[_L]}spmv_tail")
+    _f.restype = None
+    _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32]
+
+
+def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_rows=128, rows_per_lane=2, step=8,
+              tail_lanes=8):
+    """HELL (dict has hack_offsets) or ELL SpMV in the summation order of the tail-mode slab kernel."""
+    L = mat["letter"]
+    z = np.zeros(mat["rows"], NP_DTYPE[L]) if y is None else np.array(y, NP_DTYPE[L], copy=True)
+    yy = None if y is None else np.ascontiguousarray(y, NP_DTYPE[L])
+    ri = None if r_idx is None else np.ascontiguousarray(r_idx, np.int32)
+    is_hell = "hack_offsets" in mat
+    rs = mat["row_lengths"] if (is_hell or with_row_sizes) else None
+    getattr(orc, f"orc_{_LOW[L]}spmv_tail")(
+        _p(z), _p(yy), scalar(L, alpha), _p(mat["values"]), _p(mat["indices"]), mat["hack_size"] if is_hell else 0,
+        _p(mat["hack_offsets"]) if is_hell else None, 0 if is_hell else mat["pitch"], 0 if is_hell else mat["pitch"],
+        _p(rs), 0 if is_hell else mat["max_row"], _p(ri), mat["rows"], _p(np.ascontiguousarray(x, NP_DTYPE[L])),
+        scalar(L, beta), mat["base"], group_rows, rows_per_lane, step, tail_lanes)
+    return z
+
+
+def default_spmv(mat, x, y, alpha, beta, r_idx=None):
+    """The oracle in the summation order of the library's DEFAULT kernel for this matrix's type
+    (spgpu_amd/csrc/ellpack_spmv.hip launchSlabFamily): D/C tail-mode, S 8 phases, Z 2 phases."""
+    L = mat["letter"]
+    if L in TAIL_SHAPE:
+        return spmv_tail(mat, x, y, alpha, beta, r_idx=r_idx, **TAIL_SHAPE[L])
+    phases = {"S": 8, "Z": 2}[L]
+    fn = hell_spmv if "hack_offsets" in mat else ell_spmv
+    return fn(mat, x, y, alpha, beta, r_idx=r_idx, phases=phases)

@@ -77,5 +77,7 @@ def test_oell_route_matches_plain_ell(gpu):
     formats.DeviceEll(ell).spmv(gpu, z0, dy, 1.0, dx, 0.5)
     formats.DeviceEll(oell, r_idx=r_idx).spmv(gpu, z1, dy, 1.0, dx, 0.5)
     torch.cuda.synchronize()
-    assert torch.equal(z0, z1)
-    assert z1.cpu().numpy().tobytes() == O.ell_spmv(oell, x, y, 1.0, 0.5, r_idx=r_idx, phases=1).tobytes()
+    # a long row's tail is summed 64 ways from the column where its wavefront's other rows have ended, and the
+    # reordering changes which rows share a wavefront: equal within rounding, not bitwise
+    assert (z0 - z1).abs().max().item() <= 1e-13 * float(np.abs(v).max() * np.abs(x).max() * lengths.max())
+    assert z1.cpu().numpy().tobytes() == O.default_spmv(oell, x, y, 1.0, 0.5, r_idx=r_idx).tobytes()

@@ -84,4 +84,4 @@ def test_full_size_hell_fp64_properties(gpu, pattern):
     xs = x1.cpu().numpy()
     for first in (0, 4_999_936, n - 2048):
         sub = synth.hell_rows_to_host(h, first, 2048)
-        assert z1[first:first + 2048].cpu().numpy().tobytes() == O.hell_spmv(sub, xs, None, 1.0, 0.0, phases=1).tobytes()
+        assert z1[first:first + 2048].cpu().numpy().tobytes() == O.default_spmv(sub, xs, None, 1.0, 0.0).tobytes()

@@ -2,7 +2,8 @@
 golden fixtures.  Tolerance (north_star): 1e-6 (fp64) / 1e-4 (fp32) of the row magnitude;
 in addition the kernels are compared BIT FOR BIT with the oracle run in the kernel's own
 summation order (default dispatch: D/C ascending k like the reference's one-thread-per-row
-kernel, S 8 phases, Z 2 phases like the reference's two-threads-per-row kernel), which is
+kernel, with the entries of a long row's tail split 64 ways; S 8 phases; Z 2 phases like the
+reference's two-threads-per-row kernel), which is
 stricter than the contract and catches indexing slips that a tolerance would hide."""
 import ctypes as C
 import glob
@@ -16,7 +17,7 @@ import oracle_api as O
 pytestmark = pytest.mark.gpu
 
 TOL = {"S": 1e-4, "C": 1e-4, "D": 1e-6, "Z": 1e-6}
-WIDE_PHASES = {"S": 8, "D": 1, "C": 1, "Z": 2}   # default dispatch of ellpack_spmv.hip (launchSlabFamily)
+# default dispatch of ellpack_spmv.hip (launchSlabFamily): see oracle_api.default_spmv
 _ONE, _TWO = dict.fromkeys("SDCZ", 1), dict.fromkeys("SDCZ", 2)
 _PHX2 = {"S": 8, "D": 4, "C": 4, "Z": 2}       # wide kernel with 2*RPL phases (Z has RPL 1: narrow, 2 phases)
 VARIANT_PHASES = {1: _PHX2, 2: {**_ONE, "Z": 2}, 3: _TWO, 4: _ONE, 6: _PHX2, 12: {**_ONE, "Z": 2}, 13: _TWO}
@@ -71,15 +72,14 @@ def test_fixture_parity_all_formats(gpu, name):
     letter, ell, hell, hdia = _mats(g)
     alpha, beta = g["alpha"][()], g["beta"][()]
     y = g["y"] if beta != 0 else None
-    ph = WIDE_PHASES[letter]
 
     z = _run(gpu, formats.DeviceHell(hell), g["x"], y, alpha, beta)
     assert _within(z, g, letter) <= 1.0
-    assert z.tobytes() == O.hell_spmv(hell, g["x"], y, alpha, beta, phases=ph).tobytes()
+    assert z.tobytes() == O.default_spmv(hell, g["x"], y, alpha, beta).tobytes()
 
     z = _run(gpu, formats.DeviceEll(ell), g["x"], y, alpha, beta)
     assert _within(z, g, letter) <= 1.0
-    assert z.tobytes() == O.ell_spmv(ell, g["x"], y, alpha, beta, phases=ph).tobytes()
+    assert z.tobytes() == O.default_spmv(ell, g["x"], y, alpha, beta).tobytes()
 
     # rS == NULL: iterate maxNnzPerRow over the zero padding (index 0 - baseIndex may be -1: skipped)
     z = _run(gpu, formats.DeviceEll(ell, with_row_sizes=False), g["x"], y, alpha, beta)
@@ -92,20 +92,27 @@ def test_fixture_parity_all_formats(gpu, name):
         assert z.tobytes() == O.hdia_spmv(hdia, g["x"], y, alpha, beta).tobytes()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 12, 13])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 12, 13, 17])
 @pytest.mark.parametrize("name", ["powerlaw_s_b1_h64", "powerlaw_d_b0_h32", "powerlaw_c_b0_h32", "powerlaw_z_b1_h64"])
 def test_every_kernel_variant_bit_exact(gpu, name, variant, monkeypatch):
     from spgpu_amd import formats
     monkeypatch.setenv("SPGPU_SPMV_VARIANT", str(variant))
     g = _load(name)
     letter, ell, hell, _ = _mats(g)
-    ph = VARIANT_PHASES[variant][letter]   # Z (16-byte elements) has no wide form: wide requests run narrow 2x4 pipe
+    # Z (16-byte elements) has no wide form: wide requests run narrow 2x4 pipe
+    if variant == 17 and letter != "Z":
+        shape = dict(group_rows=64 * (16 // np.dtype(O.NP_DTYPE[letter]).itemsize), rows_per_lane=16 // np.dtype(O.NP_DTYPE[letter]).itemsize,
+                     step=8, tail_lanes=8)
+        want_of = lambda m, yy, b: O.spmv_tail(m, g["x"], yy, g["alpha"][()], b, **shape)
+    else:
+        ph = 2 if (variant == 17 and letter == "Z") else VARIANT_PHASES[variant][letter]
+        want_of = lambda m, yy, b: (O.hell_spmv if "hack_offsets" in m else O.ell_spmv)(m, g["x"], yy, g["alpha"][()], b, phases=ph)
     for beta in (0.0, g["beta"][()] if g["beta"][()] != 0 else 0.5):
         y = g["y"] if beta != 0 else None
         z = _run(gpu, formats.DeviceHell(hell), g["x"], y, g["alpha"][()], beta)
-        assert z.tobytes() == O.hell_spmv(hell, g["x"], y, g["alpha"][()], beta, phases=ph).tobytes()
+        assert z.tobytes() == want_of(hell, y, beta).tobytes()
         z = _run(gpu, formats.DeviceEll(ell), g["x"], y, g["alpha"][()], beta)
-        assert z.tobytes() == O.ell_spmv(ell, g["x"], y, g["alpha"][()], beta, phases=ph).tobytes()
+        assert z.tobytes() == want_of(ell, y, beta).tobytes()
 
 
 @pytest.mark.parametrize("name", ["powerlaw_d_b1_h64", "powerlaw_s_b0_h32", "powerlaw_z_b0_h32"])
@@ -114,20 +121,19 @@ def test_row_reorder_in_place_and_beta_zero_ignores_y(gpu, name):
     from spgpu_amd import formats
     g = _load(name)
     letter, ell, hell, _ = _mats(g)
-    ph = WIDE_PHASES[letter]
     rng = np.random.default_rng(3)
     perm = rng.permutation(hell["rows"]).astype(np.int32)
     alpha, beta = g["alpha"][()], (0.5 if letter in "SD" else 0.5 - 0.25j)
 
     # rIdx: row r of the storage is row rIdx[r] of y and z (hell_spmv_base_template.cuh:227-252)
     z = _run(gpu, formats.DeviceHell(hell, r_idx=perm), g["x"], g["y"], alpha, beta)
-    assert z.tobytes() == O.hell_spmv(hell, g["x"], g["y"], alpha, beta, r_idx=perm, phases=ph).tobytes()
+    assert z.tobytes() == O.default_spmv(hell, g["x"], g["y"], alpha, beta, r_idx=perm).tobytes()
     z = _run(gpu, formats.DeviceEll(ell, r_idx=perm), g["x"], g["y"], alpha, beta)
-    assert z.tobytes() == O.ell_spmv(ell, g["x"], g["y"], alpha, beta, r_idx=perm, phases=ph).tobytes()
+    assert z.tobytes() == O.default_spmv(ell, g["x"], g["y"], alpha, beta, r_idx=perm).tobytes()
 
     # z may alias y exactly (hell.h:30)
     z = _run(gpu, formats.DeviceHell(hell), g["x"], g["y"], alpha, beta, in_place=True)
-    assert z.tobytes() == O.hell_spmv(hell, g["x"], g["y"], alpha, beta, phases=ph).tobytes()
+    assert z.tobytes() == O.default_spmv(hell, g["x"], g["y"], alpha, beta).tobytes()
 
     # beta == 0 must not read y: NaN-filled y may not leak into z
     mat = formats.DeviceHell(hell)
@@ -136,7 +142,7 @@ def test_row_reorder_in_place_and_beta_zero_ignores_y(gpu, name):
     dz = torch.empty_like(dy)
     mat.spmv(gpu, dz, dy, alpha, dx, 0.0)
     torch.cuda.synchronize()
-    assert dz.cpu().numpy().tobytes() == O.hell_spmv(hell, g["x"], None, alpha, 0.0, phases=ph).tobytes()
+    assert dz.cpu().numpy().tobytes() == O.default_spmv(hell, g["x"], None, alpha, 0.0).tobytes()
 
 
 def test_unaligned_streams_take_the_narrow_kernel(gpu):

@@ -60,7 +60,7 @@ if "c3" in args.which:
                                       None, 32, n, p(x), 0.0, 0)
     t = timed(call, args.reps)
     sub = synth.ragged_rows_to_host(h, 0, 4096)
-    want = O.hell_spmv(sub, x.cpu().numpy(), None, 1.0, 0.0, phases=8)
+    want = O.default_spmv(sub, x.cpu().numpy(), None, 1.0, 0.0)
     parity = "bit-exact vs oracle on 4096 rows" if z[:4096].cpu().numpy().tobytes() == want.tobytes() else "MISMATCH"
     alg = h["nnz"] * 8 + n * (4 + 4) + n * 4 + (n // 32) * 4
     hell_bytes = h["slots"] * 8 + n * 4 + (n // 32) * 4
