@@ -20,8 +20,8 @@ OBJS      := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.hip.o,$(HIP_SRCS)) \
              $(patsubst $(CSRC)/%.cpp,$(BUILD)/%.cpp.o,$(CPP_SRCS))
 HDRS      := $(wildcard include/spgpu/*.h) $(wildcard $(CSRC)/*.h)
 
-.PHONY: all lib oracle ref clean
-all: lib oracle ref
+.PHONY: all lib oracle ref tools clean
+all: lib oracle ref tools
 
 lib: $(LIBDIR)/libspgpu.so
 
@@ -42,6 +42,13 @@ $(BUILD)/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(BUILD)
 	$(HIPCC) -x c++ $(CFLAGS) -std=c++17 -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include -c $< -o $@
 
+# Plain-C callers of the C ABI (gcc, no hipcc): the reference's ctest.c / hellPerf.cpp flows and a CG solver.
+TOOLS := tools/ctest_amd.bin tools/hellperf_amd.bin tools/cg_amd.bin
+tools: lib $(TOOLS)
+tools/%.bin: tools/%.c $(HDRS) $(LIBDIR)/libspgpu.so
+	gcc -O2 -std=gnu99 -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include -Iinclude $< -L$(LIBDIR) -lspgpu -L$(ROCM)/lib -lamdhip64 -lm \
+	    -Wl,-rpath,'$$ORIGIN/../spgpu_amd/lib' -Wl,-rpath,$(ROCM)/lib -o $@
+
 oracle:
 	$(MAKE) -C oracle liboracle.so
 
@@ -49,4 +56,4 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -rf build $(LIBDIR)/libspgpu.so oracle/liboracle.so oracle/_ref
+	rm -rf build $(LIBDIR)/libspgpu.so oracle/liboracle.so oracle/_ref tools/*.bin
