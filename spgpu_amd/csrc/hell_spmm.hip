@@ -32,6 +32,7 @@
 #include "spgpu/spmm.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 namespace spgpu {
 
@@ -56,7 +57,7 @@ __device__ inline float laneFrom(float v, int src) { return __shfl(v, src, kWave
 __device__ inline double laneFrom(double v, int src) { return __shfl(v, src, kWave); }
 __device__ inline int laneFrom(int v, int src) { return __shfl(v, src, kWave); }
 
-template <typename T, int KP, int VEC, int UNROLL>
+template <typename T, int KP, int VEC, int UNROLL, bool BRANCHY>
 __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T> a)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T>
     const int t = lane % KP;
     const int rhs0 = t * VEC;
     const T* __restrict__ X = a.X + rhs0;
+    const T* __restrict__ Xsafe = a.X + (rhs0 < a.count ? rhs0 : 0); /* lanes beyond `count` read a valid slice */
 
     T sum[KP][VEC];
 #pragma unroll
@@ -123,12 +125,17 @@ __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T>
                 }
 #pragma unroll
                 for (int i = 0; i < CHUNK; ++i) {
-                    if (col[i] >= 0 && rhs0 < a.count) {
-                        xv[i] = loadPack<false, T, VEC>(X + (long long)col[i] * a.ldX);
-                    } else {
+                    if constexpr (BRANCHY) {
+                        if (col[i] >= 0 && rhs0 < a.count) {
+                            xv[i] = loadPack<false, T, VEC>(X + (long long)col[i] * a.ldX);
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e)
-                            xv[i].v[e] = zeroOf<T>();
+                            for (int e = 0; e < VEC; ++e)
+                                xv[i].v[e] = zeroOf<T>();
+                        }
+                    } else {
+                        /* no branch: inactive slots read row 0 of X (always valid) and are discarded below */
+                        xv[i] = loadPack<false, T, VEC>(Xsafe + (long long)(col[i] >= 0 ? col[i] : 0) * a.ldX);
                     }
                 }
 #pragma unroll
@@ -169,12 +176,12 @@ __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T>
     }
 }
 
-template <typename T, int KP, int VEC, int UNROLL>
+template <typename T, int KP, int VEC, int UNROLL, bool BRANCHY = false>
 static void launchSpmm(hipStream_t stream, const SpmmArgs<T>& a)
 {
     const long long groups = ((long long)a.rows + kWave - 1) / kWave;
     const unsigned blocks = (unsigned)((groups + kSpmmThreads / kWave - 1) / (kSpmmThreads / kWave));
-    hipLaunchKernelGGL((hellSpmmKernel<T, KP, VEC, UNROLL>), dim3(blocks), dim3(kSpmmThreads), 0, stream, a);
+    hipLaunchKernelGGL((hellSpmmKernel<T, KP, VEC, UNROLL, BRANCHY>), dim3(blocks), dim3(kSpmmThreads), 0, stream, a);
 }
 
 template <typename T>
@@ -209,8 +216,18 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
         a.ldX = ldX;
         a.ldYZ = ldYZ;
         const bool pairs = pairsOk && a.count % 2 == 0;
+        const char* ev = getenv("SPGPU_SPMM_VARIANT"); /* experiments */
+        const int variant = ev && *ev ? atoi(ev) : 0;
         if (a.count > 8) {
-            if (pairs)
+            if (pairs && variant == 1)
+                launchSpmm<T, 8, 2, 2, true>(stream, a);
+            else if (pairs && variant == 2)
+                launchSpmm<T, 8, 2, 1>(stream, a);
+            else if (pairs && variant == 3)
+                launchSpmm<T, 8, 2, 4>(stream, a);
+            else if (variant == 4)
+                launchSpmm<T, 16, 1, 2>(stream, a);
+            else if (pairs)
                 launchSpmm<T, 8, 2, 2>(stream, a);
             else
                 launchSpmm<T, 16, 1, 2>(stream, a);
