@@ -11,6 +11,20 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_built()
+
+
+def _ensure_built():
+    """The built artefacts are git-ignored and normally travel with the tree; if a checkout arrives without
+    them, build them once (same toolchain on every box: hipcc for the library, gcc for oracle and tools).
+    oracle/_ref needs /root/reference and is only ever built in the build container."""
+    import subprocess
+    need = {"lib": os.path.join(ROOT, "spgpu_amd", "lib", "libspgpu.so"),
+            "oracle": os.path.join(ROOT, "oracle", "liboracle.so"),
+            "tools": os.path.join(ROOT, "tools", "cg_amd.bin")}
+    missing = [target for target, path in need.items() if not os.path.exists(path)]
+    if missing:
+        subprocess.run(["make", "-C", ROOT, *missing], check=False)
 
 
 @pytest.fixture(scope="session")
