@@ -1,0 +1,99 @@
+"""GPU: runtime properties of the C ABI that a solver relies on: calls are capturable into a HIP graph
+(no allocation or synchronisation inside the launch path), independent handles/streams do not interfere,
+and unusual hack sizes work."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _problem(seed=1, rows=3000, hs=32):
+    from spgpu_amd import formats, synth
+    lengths = synth.power_law_lengths(rows, 9.0, 70, seed=seed)
+    n, m, r, c, v = synth.random_rows_coo(rows, rows, lengths, seed=seed + 1, letter="D")
+    hell = formats.ell_to_hell(formats.coo_to_ell(n, r, c, v), hs)
+    return hell, synth.values_for("D", seed + 2, m), synth.values_for("D", seed + 3, n)
+
+
+def test_spmv_and_axpby_capture_into_a_hip_graph(gpu):
+    """One CG-like step (SpMV, axpby, axpby) captured once and replayed: results equal the eager ones."""
+    import torch
+    from spgpu_amd import capi, formats
+    hell, x, y = _problem()
+    mat = formats.DeviceHell(hell)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    dz, dw = torch.empty_like(dy), torch.empty_like(dy)
+    n = hell["rows"]
+
+    def step():
+        mat.spmv(gpu, dz, dy, 1.5, dx, -0.5)
+        capi.axpby["D"](gpu, _p(dw), n, 2.0, _p(dz), 0.25, _p(dy))
+        capi.axpby["D"](gpu, _p(dw), n, 1.0, _p(dw), -1.0, _p(dz))
+
+    side = torch.cuda.Stream()
+    capi.spgpuSetStream(gpu, C.c_void_p(side.cuda_stream))
+    with torch.cuda.stream(side):
+        step()
+    side.synchronize()
+    eager = dw.clone()
+    dw.zero_(); dz.zero_()
+    torch.cuda.synchronize()
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        # torch captures on `side`; the handle launches on the same stream, so the launches are recorded
+        step()
+    dw.zero_(); dz.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(dw, eager)
+    dy.mul_(2.0)                       # the graph reads the buffers, not captured values
+    graph.replay()
+    torch.cuda.synchronize()
+    want = O.default_spmv(hell, x, 2.0 * y, 1.5, -0.5)
+    assert dz.cpu().numpy().tobytes() == want.tobytes()
+    capi.spgpuSetStream(gpu, None)
+
+
+def test_two_handles_two_streams_interleaved(gpu):
+    """Independent handles with their own streams and reduction scratch give the single-stream answers."""
+    import torch
+    from spgpu_amd import capi, formats
+    h2 = capi.create_handle(0)
+    probs = [_problem(seed=s, rows=4000 + 500 * s) for s in (1, 2)]
+    mats = [formats.DeviceHell(p[0]) for p in probs]
+    dxs = [formats.to_device(p[1]) for p in probs]
+    dzs = [torch.empty(p[0]["rows"], dtype=torch.float64, device="cuda:0") for p in probs]
+    dots = [None, None]
+    for rep in range(20):
+        for i, handle in enumerate((gpu, h2)):
+            mats[i].spmv(handle, dzs[i], None, 1.0, dxs[i], 0.0)
+            dots[i] = capi.dot["D"](handle, probs[i][0]["rows"], _p(dzs[i]), _p(dzs[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        want = O.default_spmv(probs[i][0], probs[i][1], None, 1.0, 0.0)
+        assert dzs[i].cpu().numpy().tobytes() == want.tobytes()
+        assert abs(dots[i] - float(np.dot(want, want))) <= 1e-11 * float(np.dot(want, want))
+    capi.spgpuDestroy(h2)
+
+
+@pytest.mark.parametrize("hs", [96, 160, 48, 8])
+def test_unusual_hack_sizes(gpu, hs):
+    """hackSize a multiple of 32 beyond 32/64, and values the header does not promise (48, 8): every lane
+    derives its hack from its own row, so they work too (strips never straddle a hack when hs % RPL == 0)."""
+    from spgpu_amd import formats
+    import torch
+    hell, x, y = _problem(seed=7, rows=1000, hs=hs)
+    dz = torch.empty(hell["rows"], dtype=torch.float64, device="cuda:0")
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    formats.DeviceHell(hell).spmv(gpu, dz, dy, 1.0, dx, 0.5)
+    torch.cuda.synchronize()
+    assert dz.cpu().numpy().tobytes() == O.default_spmv(hell, x, y, 1.0, 0.5).tobytes()
