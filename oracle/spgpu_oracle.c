@@ -627,15 +627,17 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
 
 /* The MI355X slab kernel's "tail" order (spgpu_amd/csrc/ellpack_spmv.hip, TAIL): a wavefront owns
  * groupRows consecutive rows, rowsPerLane per lane.  It walks slab columns `step` at a time while more than
- * tailLanes lanes still have entries; the first column block at which <= tailLanes lanes are busy is
- * tailFrom.  A row's sum is then  (entries k < tailFrom in ascending k)  +  (entries k >= tailFrom split
- * over 64 partial sums by (k - tailFrom) mod 64, each ascending, combined pairwise p with p^1, p^2, ... p^32).
+ * tailLanes lanes still have entries (a strip of rowsPerLane rows keeps `phases` lanes busy); the first
+ * column block at which <= tailLanes lanes are busy is tailFrom.  A row's sum is then: `phases` partial sums
+ * over entries k < tailFrom by k mod phases, each ascending; entries k >= tailFrom split over 64 partial sums
+ * by (k - tailFrom) mod 64, each ascending, combined pairwise (p with p^1, ... p^32) and added to partial 0;
+ * finally the `phases` partials combined pairwise.
  * Same arithmetic and epilogue as orc_?hellspmv / orc_?ellspmv; hackOffsets == NULL selects ELL addressing. */
 #define ORC_DEFINE_TAIL(P, T)                                                                                 \
     void orc_##P##spmv_tail(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
                             const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \
                             const int* rIdx, int rows, const T* x, T beta, int baseIndex, int groupRows,      \
-                            int rowsPerLane, int step, int tailLanes)                                         \
+                            int rowsPerLane, int step, int tailLanes, int phases)                             \
     {                                                                                                         \
         for (int g0 = 0; g0 < rows; g0 += groupRows) {                                                        \
             const int gEnd = g0 + groupRows < rows ? g0 + groupRows : rows;                                   \
@@ -655,19 +657,20 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                     }                                                                                         \
                     busy += kBase < laneLongest;                                                              \
                 }                                                                                             \
-                if (busy <= tailLanes) { tailFrom = kBase; break; }                                           \
+                if (busy * phases <= tailLanes) { tailFrom = kBase; break; } /* every strip has `phases` lanes */ \
             }                                                                                                 \
             for (int i = g0; i < gEnd; ++i) {                                                                 \
                 const int len = rS ? rS[i] : maxNnz;                                                          \
                 const size_t slot0 = hackOffsets ? (size_t)hackOffsets[i / hackSize] + (size_t)(i % hackSize) : (size_t)i; \
                 const size_t vs = hackOffsets ? (size_t)hackSize : (size_t)cMPitch;                           \
                 const size_t is = hackOffsets ? (size_t)hackSize : (size_t)rPPitch;                           \
-                T sum = P##_zero();                                                                           \
+                T head[ORC_MAX_PHASES]; /* k < tailFrom: `phases` partial sums by k mod phases */             \
+                for (int p = 0; p < phases; ++p) head[p] = P##_zero();                                        \
                 for (int k = 0; k < len && k < tailFrom; ++k) {                                               \
                     const int col = rP[slot0 + (size_t)k * is] - baseIndex;                                   \
-                    if (col >= 0) sum = P##_fma(cM[slot0 + (size_t)k * vs], x[col], sum);                     \
+                    if (col >= 0) head[k % phases] = P##_fma(cM[slot0 + (size_t)k * vs], x[col], head[k % phases]); \
                 }                                                                                             \
-                if (len > tailFrom) {                                                                         \
+                if (len > tailFrom) { /* the 64-way tail sum joins the phase-0 partial before the phases combine */ \
                     T part[ORC_MAX_PHASES];                                                                   \
                     for (int p = 0; p < 64; ++p) part[p] = P##_zero();                                        \
                     for (int k = tailFrom; k < len; ++k) {                                                    \
@@ -675,9 +678,9 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                         if (col >= 0)                                                                         \
                             part[(k - tailFrom) % 64] = P##_fma(cM[slot0 + (size_t)k * vs], x[col], part[(k - tailFrom) % 64]); \
                     }                                                                                         \
-                    sum = P##_add(sum, P##_combine(part, 64));                                                \
+                    head[0] = P##_add(head[0], P##_combine(part, 64));                                        \
                 }                                                                                             \
-                P##_store(z, y, rIdx ? rIdx[i] : i, alpha, sum, beta);                                        \
+                P##_store(z, y, rIdx ? rIdx[i] : i, alpha, P##_combine(head, phases), beta);                  \
             }                                                                                                 \
         }                                                                                                     \
     }

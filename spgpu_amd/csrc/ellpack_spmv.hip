@@ -73,7 +73,8 @@ template <typename T> struct SlabArgs {
 
 constexpr int kBlockThreads = 256;
 constexpr int kWavesPerBlock = kBlockThreads / kWave;
-constexpr int kTailLanes = 8;  /* switch to whole-wave row processing when <= this many lanes are busy */
+constexpr int kTailLanes = 16; /* switch to whole-wave row processing when <= this many lanes are busy
+                                  (measured flat between 4 and 16 for the 1-phase kernel, worse above) */
 constexpr int kTailUnroll = 4; /* entries per lane in flight in tail mode */
 
 /*
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
     };
 
     constexpr int STEP = PH * UNROLL;
-    /* TAIL (PH == 1 only): when at most kTailLanes lanes of the wavefront still have entries left, the
+    /* TAIL: when at most kTailLanes lanes of the wavefront still have entries left, the
      * slab loop would run on with >= 7/8 of its lanes idle (ragged matrices: one long row keeps a whole
      * group looping).  The loop stops there and the few remaining rows are finished one at a time by the
      * WHOLE wavefront: lane l takes entries tailFrom + l, + 64, ...; the 64 partial sums are combined
@@ -214,11 +215,11 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
     }
 
     if constexpr (TAIL) {
-        static_assert(!TAIL || PH == 1, "tail mode is written for one phase");
+        /* all PH lanes of a strip share laneLongest, so they enter and leave `pending` together */
         unsigned long long pending = __ballot(tailFrom < laneLongest);
         while (pending) { /* wave-uniform */
-            const int owner = __ffsll((long long)pending) - 1;
-            pending &= pending - 1;
+            const int owner = (__ffsll((long long)pending) - 1) % LPC; /* the strip's phase-0 lane */
+            pending &= ~__ballot(sub == owner);
             const long long ownerSlab = __shfl(slab, owner, kWave);
 #pragma unroll
             for (int t = 0; t < RPL; ++t) {
@@ -345,13 +346,13 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
      * columns, prefetched (5.93 TB/s).
      * SPGPU_SPMV_VARIANT (experiments; 0 = this table):
      *   1 wide PHx2 | 2 wide 1x4 | 3 narrow 2x4 | 4 narrow 1x4 | 6 wide PHx2 pipe | 12 wide 1x8 pipe |
-     *   13 narrow 2x4 pipe | 17 wide 1x8 pipe + whole-wave tail rows
+     *   13 narrow 2x4 pipe | 17 wide 1x8 pipe + whole-wave tail rows | 18 wide PHx2 pipe + tail rows
      *   (5,7..11,14..16 exist only in -DSPGPU_TUNING_VARIANTS builds)
      * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams (default 1). */
     a.tailLanes = envInt("SPGPU_TAIL_LANES", kTailLanes);
     int variant = envInt("SPGPU_SPMV_VARIANT", 0);
     const bool nt = envInt("SPGPU_NT_LOADS", 1) != 0;
-    if (variant < 1 || variant > 17)
+    if (variant < 1 || variant > 18)
         variant = !wideOk ? 13 : (sizeof(T) == 4 ? 6 : 17);
     const bool narrowVariant = variant == 3 || variant == 4 || (variant >= 13 && variant <= 16);
     if (!wideOk && !narrowVariant)
@@ -373,6 +374,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 11: launchSlab<T, WIDE, 1, IS_HELL, 2, true>(stream, a, nt); break;
 #endif
             case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
+            case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;
             default: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true>(stream, a, nt); break; /* 17 */
             }
             return;

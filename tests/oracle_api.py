@@ -405,16 +405,16 @@ def ell_csput(ell, a_i, a_j, a_val, base):
 
 
 # ---- the slab kernel's tail-mode summation order (default fp64 / complex-fp32 kernel) ----------
-TAIL_SHAPE = {"D": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=8),
-              "C": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=8)}
+TAIL_SHAPE = {"D": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=16, phases=1),
+              "C": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=16, phases=1)}
 for _L, _T in SCALAR.items():
     _f = getattr(orc, f"orc_{_LOW[_L]}spmv_tail")
     _f.restype = None
-    _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32]
+    _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32, i32]
 
 
 def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_rows=128, rows_per_lane=2, step=8,
-              tail_lanes=8):
+              tail_lanes=16, phases=1):
     """HELL (dict has hack_offsets) or ELL SpMV in the summation order of the tail-mode slab kernel."""
     L = mat["letter"]
     z = np.zeros(mat["rows"], NP_DTYPE[L]) if y is None else np.array(y, NP_DTYPE[L], copy=True)
@@ -426,7 +426,7 @@ def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_row
         _p(z), _p(yy), scalar(L, alpha), _p(mat["values"]), _p(mat["indices"]), mat["hack_size"] if is_hell else 0,
         _p(mat["hack_offsets"]) if is_hell else None, 0 if is_hell else mat["pitch"], 0 if is_hell else mat["pitch"],
         _p(rs), 0 if is_hell else mat["max_row"], _p(ri), mat["rows"], _p(np.ascontiguousarray(x, NP_DTYPE[L])),
-        scalar(L, beta), mat["base"], group_rows, rows_per_lane, step, tail_lanes)
+        scalar(L, beta), mat["base"], group_rows, rows_per_lane, step, tail_lanes, phases)
     return z
 
 
