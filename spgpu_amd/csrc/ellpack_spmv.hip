@@ -77,6 +77,27 @@ constexpr int kTailLanes = 16; /* switch to whole-wave row processing when <= th
                                   (measured flat between 4 and 16 for the 1-phase kernel, worse above) */
 constexpr int kTailUnroll = 4; /* entries per lane in flight in tail mode */
 
+/* Cache policy of the x gathers (experiments, -DSPGPU_TUNING_VARIANTS): 0 default, 1 non-temporal,
+ * 2 agent-scope (sc1: bypasses the per-CU L1). */
+template <int POLICY, typename T> __device__ inline T loadX(const T* p)
+{
+    if constexpr (POLICY == 1) {
+        using Raw = typename RawBits<sizeof(T)>::type;
+        Raw raw = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(p));
+        T out;
+        __builtin_memcpy(&out, &raw, sizeof(T));
+        return out;
+    } else if constexpr (POLICY == 2 && sizeof(T) == 8) {
+        unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+        T out;
+        __builtin_memcpy(&out, &raw, sizeof(T));
+        return out;
+    } else {
+        return *p;
+    }
+}
+
 /*
  * RPL    rows per lane (1, or 16/sizeof(T) with 16-byte loads)
  * PH     phases: lane groups that split the entries of a row by k mod PH
@@ -84,7 +105,7 @@ constexpr int kTailUnroll = 4; /* entries per lane in flight in tail mode */
  * UNROLL slab-column loads issued back to back before the first gather
  * One wavefront owns 64/PH strips = (64/PH)*RPL consecutive rows.
  */
-template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, bool PIPE, bool TAIL>
+template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, bool PIPE, bool TAIL, int XPOLICY = 0>
 __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
             for (int t = 0; t < RPL; ++t) {
                 const int col = s.c[u].v[t] - a.baseIndex;
                 use[u][t] = k < len[t] && col >= 0;
-                xv[u][t] = x[use[u][t] ? col : 0];
+                xv[u][t] = loadX<XPOLICY>(x + (use[u][t] ? col : 0));
             }
         }
 #pragma unroll
@@ -307,17 +328,17 @@ static bool alignedTo(const void* p, size_t bytes)
     return ((uintptr_t)p % bytes) == 0;
 }
 
-template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool PIPE = false, bool TAIL = false>
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool PIPE = false, bool TAIL = false, int XPOLICY = 0>
 static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
 {
     constexpr int GROUP_ROWS = (kWave / PH) * RPL;
     const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
     const unsigned blocks = (unsigned)((groups + kWavesPerBlock - 1) / kWavesPerBlock);
     if (nt)
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE, TAIL>), dim3(blocks),
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE, TAIL, XPOLICY>), dim3(blocks),
                            dim3(kBlockThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE, TAIL>), dim3(blocks),
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE, TAIL, XPOLICY>), dim3(blocks),
                            dim3(kBlockThreads), 0, stream, a);
 }
 
@@ -352,7 +373,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     a.tailLanes = envInt("SPGPU_TAIL_LANES", kTailLanes);
     int variant = envInt("SPGPU_SPMV_VARIANT", 0);
     const bool nt = envInt("SPGPU_NT_LOADS", 1) != 0;
-    if (variant < 1 || variant > 18)
+    if (variant < 1 || variant > 20)
         variant = !wideOk ? 13 : (sizeof(T) == 4 ? 6 : 17);
     const bool narrowVariant = variant == 3 || variant == 4 || (variant >= 13 && variant <= 16);
     if (!wideOk && !narrowVariant)
@@ -372,6 +393,8 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 9: launchSlab<T, WIDE, 1, IS_HELL, 8>(stream, a, nt); break;
             case 10: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 1, true>(stream, a, nt); break;
             case 11: launchSlab<T, WIDE, 1, IS_HELL, 2, true>(stream, a, nt); break;
+            case 19: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true, 1>(stream, a, nt); break; /* 17 + nt x gathers */
+            case 20: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true, 2>(stream, a, nt); break; /* 17 + sc1 x gathers */
 #endif
             case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
             case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;

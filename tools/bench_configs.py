@@ -71,10 +71,17 @@ if "c3" in args.which:
                 padding_ratio=round(h["slots"] / h["nnz"], 3)))
     del h
     torch.cuda.empty_cache()
-    # ELL on a reduced row count (the 10 M-row ELL would be pitch*2048*8 B = 164 GB)
+    # ELL needs pitch*2048*8 B: 164 GB at 10 M rows (fits the 288 GB of one MI355X); --ell-rows scales it down,
+    # and an allocation failure falls back to a fifth of the rows
     ne = min(args.ell_rows, n) // 32 * 32
     le = lengths[:ne]
-    e = synth.ell_ragged_on_device(le, ne, "S", seed=6)
+    try:
+        e = synth.ell_ragged_on_device(le, ne, "S", seed=6)
+    except torch.OutOfMemoryError:
+        torch.cuda.empty_cache()
+        ne = ne // 5 // 32 * 32
+        le = lengths[:ne]
+        e = synth.ell_ragged_on_device(le, ne, "S", seed=6)
     he = synth.hell_ragged_on_device(le, ne, "S", 32, seed=5)
     xe, ze = synth.device_vector(ne, "S", 3), torch.empty(ne, dtype=torch.float32, device="cuda:0")
     torch.cuda.synchronize()
@@ -85,9 +92,9 @@ if "c3" in args.which:
     te, th = timed(call_e, args.reps), timed(call_h, args.reps)
     alg_e = e["nnz"] * 8 + ne * 8 + ne * 4
     common = dict(rows=ne, nnz=e["nnz"], max_len=e["max_row"])
-    report("C3 ELL fp32 power-law (reduced rows)", te, e["nnz"], alg_e,
+    report(f"C3 ELL fp32 power-law ({ne} rows)", te, e["nnz"], alg_e,
            dict(**common, footprint_GB=round((e["pitch"] * e["max_row"] * 8 + ne * 4) * 1e-9, 2)))
-    report("C3 HELL fp32 power-law (same reduced rows)", th, he["nnz"], alg_e + (ne // 32) * 4,
+    report(f"C3 HELL fp32 power-law (same {ne} rows)", th, he["nnz"], alg_e + (ne // 32) * 4,
            dict(**common, footprint_GB=round((he["slots"] * 8 + ne * 4 + ne // 32 * 4) * 1e-9, 2)))
     del e, he
     torch.cuda.empty_cache()
