@@ -105,7 +105,7 @@ template <int POLICY, typename T> __device__ inline T loadX(const T* p)
  * UNROLL slab-column loads issued back to back before the first gather
  * One wavefront owns 64/PH strips = (64/PH)*RPL consecutive rows.
  */
-template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, bool PIPE, bool TAIL, int XPOLICY = 0>
+template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PIPE, bool TAIL, int XPOLICY = 0>
 __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
@@ -177,7 +177,10 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
             }
         }
     };
-    auto consume = [&](int kBase, const Stage& s) {
+    /* consume(kBase, stage, between): gathers of the stage, then `between()`, then the multiply-adds.
+     * vmcnt retires in issue order: loads issued BEFORE the gathers are waited for together with them,
+     * loads issued AFTER them (in `between`) stay in flight while the gathers are consumed. */
+    auto consume = [&](int kBase, const Stage& s, auto&& between) {
         T xv[UNROLL][RPL];
         bool use[UNROLL][RPL];
 #pragma unroll
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
                 xv[u][t] = loadX<XPOLICY>(x + (use[u][t] ? col : 0));
             }
         }
+        between();
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
@@ -221,8 +225,13 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
         for (int kBase = 0; kBase < groupLongest; kBase += STEP) {
             if (switchToTail(kBase))
                 break;
-            fetch(kBase + STEP, nxt); /* lanes past their rows' end fetch nothing */
-            consume(kBase, cur);
+            if constexpr (PIPE == 2) {
+                /* prefetch issued after the current gathers: younger in vmcnt order, stays in flight */
+                consume(kBase, cur, [&] { fetch(kBase + STEP, nxt); });
+            } else {
+                fetch(kBase + STEP, nxt); /* lanes past their rows' end fetch nothing */
+                consume(kBase, cur, [] {});
+            }
             cur = nxt;
         }
     } else {
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
                 break;
             Stage cur;
             fetch(kBase, cur);
-            consume(kBase, cur);
+            consume(kBase, cur, [] {});
         }
     }
 
@@ -328,7 +337,7 @@ static bool alignedTo(const void* p, size_t bytes)
     return ((uintptr_t)p % bytes) == 0;
 }
 
-template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool PIPE = false, bool TAIL = false, int XPOLICY = 0>
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, int PIPE = 0, bool TAIL = false, int XPOLICY = 0>
 static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
 {
     constexpr int GROUP_ROWS = (kWave / PH) * RPL;
@@ -360,21 +369,22 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     const bool wideOk = layoutOk && alignedTo(a.cM, 16) && alignedTo(a.rP, 4 * WIDE) &&
                         a.valStride % WIDE == 0 && a.idxStride % WIDE == 0;
 
-    /* Kernel shape.  Measured on MI355X, 10 M rows x 32 nnz, banded columns (tools/sweep_hell.py,
-     * profiles/): D/C stream fastest with a lane walking whole rows, 8 slab columns per stage
-     * and the next stage prefetched (5.93 TB/s); S with 8 phases x 2 columns, prefetched
-     * (5.44 TB/s); 16-byte elements (Z) and unaligned streams take RPL = 1 with 2 phases x 4
-     * columns, prefetched (5.93 TB/s).
+    /* Kernel shape.  Measured on MI355X, 10 M rows x 32 nnz (tools/sweep_hell.py, profiles/): D/C stream
+     * fastest with a lane walking whole rows, 8 slab columns per stage, the next stage prefetched AFTER
+     * the current gathers are issued, and whole-wave tail rows (banded 5.9 TB/s, windowed columns +13 %
+     * over prefetch-before); S with 8 phases x 2 columns, same prefetch and tail (5.4-6.0 TB/s); 16-byte
+     * elements (Z) and unaligned streams take RPL = 1 with 2 phases x 4 columns (5.9 TB/s).
      * SPGPU_SPMV_VARIANT (experiments; 0 = this table):
      *   1 wide PHx2 | 2 wide 1x4 | 3 narrow 2x4 | 4 narrow 1x4 | 6 wide PHx2 pipe | 12 wide 1x8 pipe |
-     *   13 narrow 2x4 pipe | 17 wide 1x8 pipe + whole-wave tail rows | 18 wide PHx2 pipe + tail rows
+     *   13 narrow 2x4 pipe | 17 wide 1x8 pipe + whole-wave tail rows | 18 wide PHx2 pipe + tail rows |
+     *   21 = 17 and 22 = 18 with the prefetch issued after the gathers (defaults for D/C and S)
      *   (5,7..11,14..16 exist only in -DSPGPU_TUNING_VARIANTS builds)
      * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams (default 1). */
     a.tailLanes = envInt("SPGPU_TAIL_LANES", kTailLanes);
     int variant = envInt("SPGPU_SPMV_VARIANT", 0);
     const bool nt = envInt("SPGPU_NT_LOADS", 1) != 0;
-    if (variant < 1 || variant > 20)
-        variant = !wideOk ? 13 : (sizeof(T) == 4 ? 6 : 17);
+    if (variant < 1 || variant > 24)
+        variant = !wideOk ? 13 : (sizeof(T) == 4 ? 22 : 21);
     const bool narrowVariant = variant == 3 || variant == 4 || (variant >= 13 && variant <= 16);
     if (!wideOk && !narrowVariant)
         variant = 13;
@@ -393,12 +403,16 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 9: launchSlab<T, WIDE, 1, IS_HELL, 8>(stream, a, nt); break;
             case 10: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 1, true>(stream, a, nt); break;
             case 11: launchSlab<T, WIDE, 1, IS_HELL, 2, true>(stream, a, nt); break;
+            case 23: launchSlab<T, WIDE, 1, IS_HELL, 4, 2, true>(stream, a, nt); break;
+            case 24: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 4, 2, true>(stream, a, nt); break;
             case 19: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true, 1>(stream, a, nt); break; /* 17 + nt x gathers */
             case 20: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true, 2>(stream, a, nt); break; /* 17 + sc1 x gathers */
 #endif
             case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
+            case 17: launchSlab<T, WIDE, 1, IS_HELL, 8, 1, true>(stream, a, nt); break;
+            case 22: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true>(stream, a, nt); break;
             case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;
-            default: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true>(stream, a, nt); break; /* 17 */
+            default: launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true>(stream, a, nt); break; /* 21 */
             }
             return;
         }
@@ -412,7 +426,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     case 15: launchSlab<T, 1, 2, IS_HELL, 8>(stream, a, nt); break;
     case 16: launchSlab<T, 1, 4, IS_HELL, 2, true>(stream, a, nt); break;
 #endif
-    default: launchSlab<T, 1, 2, IS_HELL, 4, true>(stream, a, nt); break; /* 13 */
+    default: launchSlab<T, 1, 2, IS_HELL, 4, 2>(stream, a, nt); break; /* 13 */
     }
 }
 

@@ -406,7 +406,8 @@ def ell_csput(ell, a_i, a_j, a_val, base):
 
 # ---- the slab kernel's tail-mode summation order (default fp64 / complex-fp32 kernel) ----------
 TAIL_SHAPE = {"D": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=16, phases=1),
-              "C": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=16, phases=1)}
+              "C": dict(group_rows=128, rows_per_lane=2, step=8, tail_lanes=16, phases=1),
+              "S": dict(group_rows=32, rows_per_lane=4, step=16, tail_lanes=16, phases=8)}
 for _L, _T in SCALAR.items():
     _f = getattr(orc, f"orc_{_LOW[_L]}spmv_tail")
     _f.restype = None
@@ -432,10 +433,10 @@ def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_row
 
 def default_spmv(mat, x, y, alpha, beta, r_idx=None):
     """The oracle in the summation order of the library's DEFAULT kernel for this matrix's type
-    (spgpu_amd/csrc/ellpack_spmv.hip launchSlabFamily): D/C tail-mode, S 8 phases, Z 2 phases."""
+    (spgpu_amd/csrc/ellpack_spmv.hip launchSlabFamily): D/C one phase + tail, S 8 phases + tail, Z 2 phases."""
     L = mat["letter"]
     if L in TAIL_SHAPE:
         return spmv_tail(mat, x, y, alpha, beta, r_idx=r_idx, **TAIL_SHAPE[L])
-    phases = {"S": 8, "Z": 2}[L]
+    phases = {"Z": 2}[L]
     fn = hell_spmv if "hack_offsets" in mat else ell_spmv
     return fn(mat, x, y, alpha, beta, r_idx=r_idx, phases=phases)
