@@ -1,0 +1,64 @@
+#pragma once
+/*
+ * Device-side format construction: COO -> ELL and COO -> HELL entirely in HBM.
+ * NEW: the reference converts on ONE host thread
+ * (ell.c:39-80, hell.c:46-104) and uploads; for the 320 M nonzeros of BASELINE
+ * configs[1] that is seconds of CPU time and a 3.8 GB PCIe copy per matrix.
+ * These routines produce arrays that are BYTE-IDENTICAL to what
+ * computeEllRowLenghts / cooToEll / computeHellAllocSize / ellToHell produce for
+ * the same COO input (any entry order, duplicates kept, k-th entry of a row =
+ * k-th occurrence in COO order), given destination arrays zeroed by the caller.
+ *
+ * All array arguments are DEVICE pointers unless marked host.  The calls run on
+ * handle->currentStream; the two "plan" calls return host scalars and therefore
+ * synchronise that stream.  `work` is caller-provided scratch of
+ * spgpuCooConvertWorkBytes(rows, nnz) bytes.
+ *
+ * Method: row lengths by atomic histogram; exclusive scan; entries bucketed per
+ * row with an atomic cursor (arbitrary order inside a row); the position k of an
+ * entry inside its row is then recomputed as the number of entries of the same
+ * row with a smaller COO index (an exact, order-independent count), which
+ * restores the reference's encounter order without a sort.
+ */
+#include "core.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Bytes of scratch the conversions below need. */
+size_t spgpuCooConvertWorkBytes(int rowsCount, int nonZerosCount);
+
+/* Pass 1 (device counterpart of computeEllRowLenghts, ell.c:5-31): fills rowLengths[rowsCount] on the device,
+ * returns the longest row in *maxRowSize (host).  Leaves in `work` the per-row buckets the fill calls use.
+ * Returns SPGPU_UNSUPPORTED if a COO row index lies outside [cooBaseIndex, cooBaseIndex + rowsCount). */
+spgpuStatus_t spgpuCooRowLengthsDevice(spgpuHandle_t handle, __device int* rowLengths, __host int* maxRowSize,
+                                       int rowsCount, int nonZerosCount, const __device int* cooRowIndices,
+                                       int cooBaseIndex, __device void* work);
+
+/* Pass 2a (device counterpart of cooToEll, ell.c:39-80).  Needs `work` as left by spgpuCooRowLengthsDevice for the
+ * same COO arrays.  elementSize is spgpuSizeOf(type): 4, 8 or 16. */
+spgpuStatus_t spgpuCooToEllDevice(spgpuHandle_t handle, __device void* ellValues, __device int* ellIndices,
+                                  int ellValuesPitch, int ellIndicesPitch, int ellBaseIndex, int rowsCount,
+                                  int nonZerosCount, const __device int* cooRowIndices,
+                                  const __device int* cooColsIndices, const __device void* cooValues,
+                                  int cooBaseIndex, spgpuType_t valuesType, const __device int* rowLengths,
+                                  __device void* work);
+
+/* HELL plan (device counterpart of computeHellAllocSize + the hackOffsets part of ellToHell, hell.c:4-44,64-100):
+ * fills hackOffsets[ceil(rows/hackSize)] on the device, returns allocationHeight (slots = hackSize * height) on the host. */
+spgpuStatus_t spgpuHellPlanDevice(spgpuHandle_t handle, __host int* allocationHeight, __device int* hackOffsets,
+                                  int hackSize, int rowsCount, const __device int* rowLengths, __device void* work);
+
+/* Pass 2b: COO -> HELL directly (equals cooToEll followed by ellToHell).  Needs `work` as left by
+ * spgpuCooRowLengthsDevice and hackOffsets from spgpuHellPlanDevice. */
+spgpuStatus_t spgpuCooToHellDevice(spgpuHandle_t handle, __device void* hellValues, __device int* hellIndices,
+                                   const __device int* hackOffsets, int hackSize, int hellBaseIndex, int rowsCount,
+                                   int nonZerosCount, const __device int* cooRowIndices,
+                                   const __device int* cooColsIndices, const __device void* cooValues,
+                                   int cooBaseIndex, spgpuType_t valuesType, const __device int* rowLengths,
+                                   __device void* work);
+
+#ifdef __cplusplus
+}
+#endif

@@ -167,6 +167,14 @@ diaToHdia = _decl("diaToHdia", None, [ptr, ptr, ptr, i32, ptr, ptr, i32, i32, i3
 ellToOell = _decl("ellToOell", None, [ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32])
 
 
+# ---- convert_device.h (new: COO -> ELL / HELL in HBM) -----------------------------------------------
+spgpuCooConvertWorkBytes = _decl("spgpuCooConvertWorkBytes", C.c_size_t, [i32, i32])
+spgpuCooRowLengthsDevice = _decl("spgpuCooRowLengthsDevice", i32, [Handle, ptr, C.POINTER(i32), i32, i32, ptr, i32, ptr])
+spgpuCooToEllDevice = _decl("spgpuCooToEllDevice", i32, [Handle, ptr, ptr, i32, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, ptr, ptr])
+spgpuHellPlanDevice = _decl("spgpuHellPlanDevice", i32, [Handle, C.POINTER(i32), ptr, i32, i32, ptr, ptr])
+spgpuCooToHellDevice = _decl("spgpuCooToHellDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, ptr, ptr])
+
+
 def create_handle(device=0):
     h = Handle()
     status = spgpuCreate(C.byref(h), device)
