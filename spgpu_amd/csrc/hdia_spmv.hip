@@ -50,9 +50,7 @@ template <typename T> struct HdiaArgs {
 };
 
 
-/* XWIDE: read the RPL consecutive x values of a strip with one (element-aligned) wide load when the
- * whole strip is in range. */
-template <typename T, int RPL, bool NT, int UNROLL, bool XWIDE, int kHdiaThreads>
+template <typename T, int RPL, bool NT, int UNROLL, int kHdiaThreads>
 __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T> a)
 {
     const unsigned block = a.xcdOrder == 0 ? blockIdx.x
@@ -114,18 +112,11 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
         for (int u = 0; u < UNROLL; ++u) {
             const long long col0 = row0 + off[u];
             const bool dLive = dBase + u < diags;
-            if (XWIDE && RPL > 1 && dLive && stripInside && col0 >= 0 && col0 + RPL <= a.cols) {
-                xv[u] = loadPackElemAligned<T, RPL>(x + col0);
 #pragma unroll
-                for (int t = 0; t < RPL; ++t)
-                    use[u][t] = true;
-            } else {
-#pragma unroll
-                for (int t = 0; t < RPL; ++t) {
-                    const long long col = col0 + t;
-                    use[u][t] = dLive && row0 + t < a.rows && col >= 0 && col < a.cols;
-                    xv[u].v[t] = x[use[u][t] ? col : 0];
-                }
+            for (int t = 0; t < RPL; ++t) {
+                const long long col = col0 + t;
+                use[u][t] = dLive && row0 + t < a.rows && col >= 0 && col < a.cols;
+                xv[u].v[t] = x[use[u][t] ? col : 0];
             }
         }
 #pragma unroll
@@ -163,29 +154,29 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
     }
 }
 
-template <typename T, int RPL, int UNROLL, bool XWIDE, int kHdiaThreads>
+template <typename T, int RPL, int UNROLL, int kHdiaThreads>
 static void launchHdiaSized(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
 {
     const long long strips = ((long long)a.rows + RPL - 1) / RPL;
     const unsigned blocks = (unsigned)((strips + kHdiaThreads - 1) / kHdiaThreads);
     if (nt)
-        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, true, UNROLL, XWIDE, kHdiaThreads>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
+        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, true, UNROLL, kHdiaThreads>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, false, UNROLL, XWIDE, kHdiaThreads>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
+        hipLaunchKernelGGL((hdiaSpmvKernel<T, RPL, false, UNROLL, kHdiaThreads>), dim3(blocks), dim3(kHdiaThreads), 0, stream, a);
 }
 
-template <typename T, int RPL, int UNROLL, bool XWIDE>
+template <typename T, int RPL, int UNROLL>
 static void launchHdia(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
 {
     /* SPGPU_HDIA_BLOCK (experiments): workgroup size 256 (default) / 512 / 1024 */
     const char* bs = getenv("SPGPU_HDIA_BLOCK");
     const int block = bs && *bs ? atoi(bs) : 256;
     if (block == 1024)
-        launchHdiaSized<T, RPL, UNROLL, XWIDE, 1024>(stream, a, nt);
+        launchHdiaSized<T, RPL, UNROLL, 1024>(stream, a, nt);
     else if (block == 512)
-        launchHdiaSized<T, RPL, UNROLL, XWIDE, 512>(stream, a, nt);
+        launchHdiaSized<T, RPL, UNROLL, 512>(stream, a, nt);
     else
-        launchHdiaSized<T, RPL, UNROLL, XWIDE, 256>(stream, a, nt);
+        launchHdiaSized<T, RPL, UNROLL, 256>(stream, a, nt);
 }
 
 template <typename T, typename ApiT>
@@ -222,23 +213,20 @@ static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     if constexpr (WIDE > 1) {
         if (wideOk) {
             a.wideIO = ((uintptr_t)z % 16 == 0) && ((uintptr_t)y % 16 == 0);
-            /* SPGPU_HDIA_VARIANT (experiments): 1 = 4 diagonals/stage, 2 = 8 (default), 3 = 8 + paired x loads.
-             * Measured on 512^3 (tools/ab_hdia.py): all within 1 %; XCD-contiguous block orders and
-             * workgroups of 512/1024 lanes are 2-13 % slower than the hardware order with 256. */
+            /* SPGPU_HDIA_VARIANT (experiments): 1 = 4 diagonals/stage, otherwise 8 (default).  Measured on 512^3
+             * (tools/ab_hdia.py, profiles/): within 1 % of each other; XCD-contiguous block orders and
+             * workgroups of 512/1024 lanes are 2-13 % slower than the hardware order with 256 lanes. */
             const char* hv = getenv("SPGPU_HDIA_VARIANT");
-            const int variant = hv && *hv ? atoi(hv) : 0;
-            if (variant == 1)
-                launchHdia<T, WIDE, 4, false>(stream, a, nt);
-            else if (variant == 3)
-                launchHdia<T, WIDE, 8, true>(stream, a, nt);
+            if (hv && *hv == '1')
+                launchHdia<T, WIDE, 4>(stream, a, nt);
             else
-                launchHdia<T, WIDE, 8, false>(stream, a, nt);
+                launchHdia<T, WIDE, 8>(stream, a, nt);
             spgpuDebugCheck(handle, "hdiaspmv");
             return;
         }
     }
     a.wideIO = 1;
-    launchHdia<T, 1, 8, false>(stream, a, nt);
+    launchHdia<T, 1, 8>(stream, a, nt);
     spgpuDebugCheck(handle, "hdiaspmv");
 }
 

@@ -44,7 +44,6 @@ static int l1MaxBlocks()
     }
     return cached;
 }
-#define kL1MaxBlocks (l1MaxBlocks())
 
 /* ---- axpby ---------------------------------------------------------------
  * Expression trees (reference): S/D  alpha*x + beta*y   (daxpby.cu:40-43)
@@ -124,7 +123,7 @@ static void axpbyLaunch(spgpuHandle_t handle, ApiT* zApi, int n, ApiT betaApi, A
                       (!hasBeta || (uintptr_t)y % 16 == 0) && (count == 1 || pitch % WIDE == 0);
     const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
     long long blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
-    const long long cap = kL1MaxBlocks / (count < kL1MaxBlocks ? count : kL1MaxBlocks);
+    const long long cap = l1MaxBlocks() / (count < l1MaxBlocks() ? count : l1MaxBlocks());
     if (blocks > (cap > 1 ? cap : 1))
         blocks = cap > 1 ? cap : 1;
     const dim3 grid((unsigned)blocks, (unsigned)count);
@@ -414,7 +413,7 @@ static void mapLaunch(spgpuHandle_t handle, ApiT* outApi, int n, ApiT alphaApi, 
                       (count == 1 || pitch % WIDE == 0);
     const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
     long long blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
-    const long long cap = kL1MaxBlocks / (count < kL1MaxBlocks ? count : kL1MaxBlocks);
+    const long long cap = l1MaxBlocks() / (count < l1MaxBlocks() ? count : l1MaxBlocks());
     if (blocks > (cap > 1 ? cap : 1))
         blocks = cap > 1 ? cap : 1;
     const dim3 grid((unsigned)blocks, (unsigned)count);
@@ -481,7 +480,7 @@ template <typename T> __global__ __launch_bounds__(kL1Threads) void fillKernel(T
 static unsigned sparseGrid(long long count)
 {
     long long blocks = (count + kL1Threads - 1) / kL1Threads;
-    return (unsigned)(blocks > 4 * kL1MaxBlocks ? 4 * kL1MaxBlocks : (blocks < 1 ? 1 : blocks));
+    return (unsigned)(blocks > 4 * l1MaxBlocks() ? 4 * l1MaxBlocks() : (blocks < 1 ? 1 : blocks));
 }
 
 template <typename T, typename ApiT>

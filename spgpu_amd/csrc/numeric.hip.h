@@ -102,18 +102,6 @@ template <bool NT, typename E, int N> __device__ inline Pack<E, N> loadPack(cons
     return out;
 }
 
-/* The same move from an address that is only aligned to sizeof(E): gfx950 runs global memory in
- * unaligned-access mode, so this is still one wide load when the compiler is told the truth
- * about the alignment. */
-template <typename E, int N> __device__ inline Pack<E, N> loadPackElemAligned(const E* p)
-{
-    struct __attribute__((packed, aligned(alignof(E)))) Loose { E v[N]; };
-    const Loose raw = *reinterpret_cast<const Loose*>(p);
-    Pack<E, N> out;
-    __builtin_memcpy(&out, &raw, sizeof(out));
-    return out;
-}
-
 template <typename E, int N> __device__ inline void storePack(E* p, const Pack<E, N>& value)
 {
     using Raw = typename RawBits<sizeof(E) * N>::type;
