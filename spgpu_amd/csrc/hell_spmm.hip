@@ -48,6 +48,7 @@ template <typename T> struct SpmmArgs {
     T alpha, beta;
     int rows, baseIndex, hackSize;
     int count;      /* right-hand sides in this pass (<= KP*VEC) */
+    int tileRows;   /* tiled kernel: X rows the LDS tile can hold */
     long long ldX, ldYZ;
 };
 
@@ -57,60 +58,41 @@ __device__ inline float laneFrom(float v, int src) { return __shfl(v, src, kWave
 __device__ inline double laneFrom(double v, int src) { return __shfl(v, src, kWave); }
 __device__ inline int laneFrom(int v, int src) { return __shfl(v, src, kWave); }
 
-template <typename T, int KP, int VEC, int UNROLL, bool BRANCHY>
-__global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T> a)
+/* The accumulation loop shared by both kernels.
+ * FROM_LDS == false: X rows are read from global memory (through L1/L2).
+ * FROM_LDS == true : X rows come from the workgroup's LDS tile.  LDS reads retire on lgkmcnt, global loads on
+ *                    vmcnt, and each counter retires in issue order -- so only in this form can the (coef, col)
+ *                    pairs of the NEXT slab columns be requested from HBM at the top of an iteration and stay in
+ *                    flight while the current columns are consumed (with global X reads a wait for them would
+ *                    also wait for the older prefetch: measured, profiles/r01b_ab_spmm_pipelined.txt). */
+template <typename T, int KP, int VEC, int UNROLL, bool FROM_LDS>
+__device__ inline void spmmAccumulate(const SpmmArgs<T>& a, int lane, int myLen, int groupLongest,
+                                      const T* __restrict__ vals, const int* __restrict__ idxs,
+                                      const T* __restrict__ tile, int tileFirst, T (&sum)[KP][VEC])
 {
-    const int lane = threadIdx.x & (kWave - 1);
-    const long long group = (long long)blockIdx.x * (kSpmmThreads / kWave) + (threadIdx.x >> 6);
-    const long long groupRow0 = group * kWave;
-    if (groupRow0 >= a.rows)
-        return; /* whole wavefront leaves together */
-
-    /* ---- load role: this lane's row ---- */
-    const long long myRow = groupRow0 + lane;
-    int myLen = 0;
-    long long slab = 0;
-    if (myRow < a.rows) {
-        const unsigned r = (unsigned)myRow, hs = (unsigned)a.hackSize;
-        const unsigned hack = r / hs;
-        slab = (long long)a.hackOffsets[hack] + (r - hack * hs);
-        myLen = a.rS[myRow];
-    }
-    const int groupLongest = waveMax(myLen);
-    const T* __restrict__ vals = a.cM + slab;
-    const int* __restrict__ idxs = a.rP + slab;
-
-    /* ---- team role ---- */
+    constexpr int TILE_LD = KP * VEC;
     const int team = lane / KP;
-    const int t = lane % KP;
-    const int rhs0 = t * VEC;
-    const T* __restrict__ X = a.X + rhs0;
-    const T* __restrict__ Xsafe = a.X + (rhs0 < a.count ? rhs0 : 0); /* lanes beyond `count` read a valid slice */
+    const int rhs0 = (lane % KP) * VEC;
+    const int rhsSafe = rhs0 < a.count ? rhs0 : 0; /* lanes beyond `count` read a valid slice, result discarded */
+    const T* __restrict__ Xsafe = a.X + rhsSafe;
 
-    T sum[KP][VEC];
-#pragma unroll
-    for (int i = 0; i < KP; ++i)
-#pragma unroll
-        for (int e = 0; e < VEC; ++e)
-            sum[i][e] = zeroOf<T>();
-
-    for (int kBase = 0; kBase < groupLongest; kBase += UNROLL) {
-        T coefMine[UNROLL];
-        int colMine[UNROLL]; /* -1: no entry */
+    auto fetch = [&](int kBase, T* coef, int* col) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = kBase + u;
             if (k < myLen) {
-                coefMine[u] = vals[(long long)k * a.hackSize];
-                colMine[u] = idxs[(long long)k * a.hackSize] - a.baseIndex;
+                coef[u] = vals[(long long)k * a.hackSize];
+                col[u] = idxs[(long long)k * a.hackSize] - a.baseIndex;
             } else {
-                coefMine[u] = zeroOf<T>();
-                colMine[u] = -1;
+                coef[u] = zeroOf<T>();
+                col[u] = -1; /* no entry */
             }
         }
+    };
+    auto consume = [&](const T* coefMine, const int* colMine) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            /* CHUNK rows of the team at a time: CHUNK gathers in flight per lane */
+            /* CHUNK rows of the team at a time: CHUNK X-row reads in flight per lane */
             constexpr int CHUNK = KP < 4 ? KP : 4;
 #pragma unroll
             for (int i0 = 0; i0 < KP; i0 += CHUNK) {
@@ -125,31 +107,53 @@ __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T>
                 }
 #pragma unroll
                 for (int i = 0; i < CHUNK; ++i) {
-                    if constexpr (BRANCHY) {
-                        if (col[i] >= 0 && rhs0 < a.count) {
-                            xv[i] = loadPack<false, T, VEC>(X + (long long)col[i] * a.ldX);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < VEC; ++e)
-                                xv[i].v[e] = zeroOf<T>();
-                        }
-                    } else {
-                        /* no branch: inactive slots read row 0 of X (always valid) and are discarded below */
+                    /* no branch: inactive slots read a valid row and are discarded below */
+                    if constexpr (FROM_LDS)
+                        xv[i] = loadPack<false, T, VEC>(tile + (col[i] >= 0 ? col[i] - tileFirst : 0) * TILE_LD + rhsSafe);
+                    else
                         xv[i] = loadPack<false, T, VEC>(Xsafe + (long long)(col[i] >= 0 ? col[i] : 0) * a.ldX);
-                    }
                 }
 #pragma unroll
                 for (int i = 0; i < CHUNK; ++i)
 #pragma unroll
                     for (int e = 0; e < VEC; ++e)
                         sum[i0 + i][e] = pick(col[i] >= 0, mulAdd(coef[i], xv[i].v[e], sum[i0 + i][e]), sum[i0 + i][e]);
-                /* keep the scheduler from hoisting every chunk's shuffles and gathers to the top:
+                /* keep the scheduler from hoisting every chunk's shuffles and reads to the top:
                  * that costs registers (occupancy), not latency -- other wavefronts cover it */
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
+    };
 
+    T coefMine[UNROLL];
+    int colMine[UNROLL];
+    if constexpr (FROM_LDS) {
+        T coefNext[UNROLL];
+        int colNext[UNROLL];
+        fetch(0, coefMine, colMine);
+        for (int kBase = 0; kBase < groupLongest; kBase += UNROLL) {
+            fetch(kBase + UNROLL, coefNext, colNext);
+            consume(coefMine, colMine);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                coefMine[u] = coefNext[u];
+                colMine[u] = colNext[u];
+            }
+        }
+    } else {
+        for (int kBase = 0; kBase < groupLongest; kBase += UNROLL) {
+            fetch(kBase, coefMine, colMine);
+            consume(coefMine, colMine);
+        }
+    }
+}
+
+/* Epilogue shared by both kernels: team g writes rows g*KP .. g*KP+KP-1, lane t the rhs t*VEC .. */
+template <typename T, int KP, int VEC>
+__device__ inline void spmmStore(const SpmmArgs<T>& a, int lane, long long groupRow0, T (&sum)[KP][VEC])
+{
+    const int team = lane / KP;
+    const int rhs0 = (lane % KP) * VEC;
     if (rhs0 >= a.count)
         return;
     const bool hasBeta = isNotZero(a.beta);
@@ -176,12 +180,127 @@ __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T>
     }
 }
 
-template <typename T, int KP, int VEC, int UNROLL, bool BRANCHY = false>
-static void launchSpmm(hipStream_t stream, const SpmmArgs<T>& a)
+/* TILED == false: plain kernel.  TILED == true: the workgroup first finds the window of X rows its 256 matrix rows
+ * touch; if the window fits the LDS tile (banded / FEM-like matrices) it is copied into LDS once, coalesced, and the
+ * accumulation reads X from there (LDS: 256 B/clk/CU, vector L1: 64); otherwise it accumulates from global memory. */
+template <typename T, int KP, int VEC, int UNROLL, bool TILED>
+__global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T> a)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char spmmLds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long group = (long long)blockIdx.x * (kSpmmThreads / kWave) + (threadIdx.x >> 6);
+    const long long groupRow0 = group * kWave;
+    if constexpr (!TILED) {
+        if (groupRow0 >= a.rows)
+            return; /* whole wavefront leaves together (the tiled form has workgroup barriers: everyone stays) */
+    }
+
+    /* ---- load role: this lane's row ---- */
+    const long long myRow = groupRow0 + lane;
+    int myLen = 0;
+    long long slab = 0;
+    if (myRow < a.rows) {
+        const unsigned r = (unsigned)myRow, hs = (unsigned)a.hackSize;
+        const unsigned hack = r / hs;
+        slab = (long long)a.hackOffsets[hack] + (r - hack * hs);
+        myLen = a.rS[myRow];
+    }
+    const int groupLongest = waveMax(myLen);
+    const T* __restrict__ vals = a.cM + slab;
+    const int* __restrict__ idxs = a.rP + slab;
+
+    T sum[KP][VEC];
+#pragma unroll
+    for (int i = 0; i < KP; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            sum[i][e] = zeroOf<T>();
+
+    if constexpr (TILED) {
+        constexpr int TILE_LD = KP * VEC;
+        T* const tile = reinterpret_cast<T*>(spmmLds);
+        __shared__ int waveLo[kSpmmThreads / kWave], waveHi[kSpmmThreads / kWave];
+        /* pass 1: column window of the workgroup (the indices are read again below, out of L2).
+         * First a probe on slab column 0 only (one coalesced load): scattered matrices already span more than
+         * the tile there and skip the full scan; then 8 independent loads per trip over all columns. */
+        auto blockWindow = [&](int& lo, int& hi) {
+#pragma unroll
+            for (int m = 1; m < kWave; m <<= 1) {
+                const int olo = laneXor(lo, m), ohi = laneXor(hi, m);
+                lo = olo < lo ? olo : lo;
+                hi = ohi > hi ? ohi : hi;
+            }
+            __syncthreads(); /* previous use of waveLo/waveHi is over */
+            if (lane == 0) {
+                waveLo[threadIdx.x >> 6] = lo;
+                waveHi[threadIdx.x >> 6] = hi;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < kSpmmThreads / kWave; ++w) {
+                lo = waveLo[w] < lo ? waveLo[w] : lo;
+                hi = waveHi[w] > hi ? waveHi[w] : hi;
+            }
+        };
+        int lo = 0x7fffffff, hi = -1;
+        if (myLen > 0) {
+            const int c = idxs[0] - a.baseIndex;
+            if (c >= 0)
+                lo = hi = c;
+        }
+        blockWindow(lo, hi);
+        const bool worthScanning = hi < lo || (long long)hi - lo < a.tileRows; /* workgroup-uniform */
+        if (worthScanning) {
+            for (int k0 = 1; k0 < myLen; k0 += 8) {
+                int c[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    c[u] = k0 + u < myLen ? idxs[(long long)(k0 + u) * a.hackSize] - a.baseIndex : -1;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (c[u] >= 0) {
+                        lo = c[u] < lo ? c[u] : lo;
+                        hi = c[u] > hi ? c[u] : hi;
+                    }
+                }
+            }
+            blockWindow(lo, hi);
+        }
+        const bool useTile = worthScanning && hi >= lo && (long long)hi - lo < a.tileRows; /* workgroup-uniform */
+        if (useTile) {
+            const int window = hi - lo + 1;
+            /* KP lanes copy one X row, VEC elements (16 bytes) each */
+            for (int i = threadIdx.x; i < window * KP; i += kSpmmThreads) {
+                const int r = i / KP, piece = i % KP;
+                if (piece * VEC < a.count)
+                    storePack<T, VEC>(tile + r * TILE_LD + piece * VEC,
+                                      loadPack<false, T, VEC>(a.X + (long long)(lo + r) * a.ldX + piece * VEC));
+            }
+        }
+        __syncthreads();
+        if (useTile)
+            spmmAccumulate<T, KP, VEC, UNROLL, true>(a, lane, myLen, groupLongest, vals, idxs, tile, lo, sum);
+        else
+            spmmAccumulate<T, KP, VEC, UNROLL, false>(a, lane, myLen, groupLongest, vals, idxs, tile, 0, sum);
+        if (groupRow0 >= a.rows)
+            return;
+    } else {
+        spmmAccumulate<T, KP, VEC, UNROLL, false>(a, lane, myLen, groupLongest, vals, idxs, nullptr, 0, sum);
+    }
+    spmmStore<T, KP, VEC>(a, lane, groupRow0, sum);
+}
+
+constexpr int kSpmmTileBytes = 48 * 1024; /* three workgroups per CU keep their tiles in the 160 KiB LDS */
+
+template <typename T, int KP, int VEC, int UNROLL, bool TILED = false>
+static void launchSpmm(hipStream_t stream, const SpmmArgs<T>& in)
+{
+    SpmmArgs<T> a = in;
     const long long groups = ((long long)a.rows + kWave - 1) / kWave;
     const unsigned blocks = (unsigned)((groups + kSpmmThreads / kWave - 1) / (kSpmmThreads / kWave));
-    hipLaunchKernelGGL((hellSpmmKernel<T, KP, VEC, UNROLL, BRANCHY>), dim3(blocks), dim3(kSpmmThreads), 0, stream, a);
+    a.tileRows = TILED ? kSpmmTileBytes / (KP * VEC * (int)sizeof(T)) : 0;
+    hipLaunchKernelGGL((hellSpmmKernel<T, KP, VEC, UNROLL, TILED>), dim3(blocks), dim3(kSpmmThreads),
+                       TILED ? kSpmmTileBytes : 0, stream, a);
 }
 
 template <typename T>
@@ -215,20 +334,21 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
         a.count = count - first < 16 ? count - first : 16;
         a.ldX = ldX;
         a.ldYZ = ldYZ;
+        a.tileRows = 0;
         const bool pairs = pairsOk && a.count % 2 == 0;
         const char* ev = getenv("SPGPU_SPMM_VARIANT"); /* experiments */
         const int variant = ev && *ev ? atoi(ev) : 0;
         if (a.count > 8) {
             if (pairs && variant == 1)
-                launchSpmm<T, 8, 2, 2, true>(stream, a);
+                launchSpmm<T, 8, 2, 2>(stream, a);          /* plain: X rows through L1 */
             else if (pairs && variant == 2)
-                launchSpmm<T, 8, 2, 1>(stream, a);
+                launchSpmm<T, 8, 2, 4, true>(stream, a);    /* tiled, 4 slab columns per stage */
             else if (pairs && variant == 3)
                 launchSpmm<T, 8, 2, 4>(stream, a);
             else if (variant == 4)
                 launchSpmm<T, 16, 1, 2>(stream, a);
             else if (pairs)
-                launchSpmm<T, 8, 2, 2>(stream, a);
+                launchSpmm<T, 8, 2, 2, true>(stream, a);    /* default: X window staged in LDS when it fits */
             else
                 launchSpmm<T, 16, 1, 2>(stream, a);
         } else if (a.count > 4) {
