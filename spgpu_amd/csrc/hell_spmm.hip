@@ -27,6 +27,7 @@
  * rows*4 + hacks*4, plus count * (cols + rows*(1+[beta!=0])) * sizeof(T).
  */
 #include "numeric.hip.h"
+#include <type_traits>
 #include "spgpu_internal.h"
 
 #include "spgpu/spmm.h"
@@ -53,6 +54,7 @@ template <typename T> struct SpmmArgs {
 };
 
 constexpr int kSpmmThreads = 256;
+constexpr int kSpmmTileBytes = 43 * 1024; /* X tile; tile + padded record slots = 52 KiB, so three workgroups fit the 160 KiB LDS of a CU */
 
 __device__ inline float laneFrom(float v, int src) { return __shfl(v, src, kWave); }
 __device__ inline double laneFrom(double v, int src) { return __shfl(v, src, kWave); }
@@ -65,16 +67,49 @@ __device__ inline int laneFrom(int v, int src) { return __shfl(v, src, kWave); }
  *                    pairs of the NEXT slab columns be requested from HBM at the top of an iteration and stay in
  *                    flight while the current columns are consumed (with global X reads a wait for them would
  *                    also wait for the older prefetch: measured, profiles/r01b_ab_spmm_pipelined.txt). */
+/* A 16-byte LDS read is served in 16-lane groups over 64 banks (256 B): two teams whose records lie 128 B apart
+ * hit the same banks.  One pad record after every 8 shifts the teams of a group onto different banks
+ * (SQ_LDS_BANK_CONFLICT was 58 % of the LDS cycles without it). */
+constexpr int kSpmmStage = 2; /* slab columns published to LDS and consumed at a time */
+constexpr int kRecordPadEvery = 8;
+constexpr int kRecordsPerColumn = kWave + kWave / kRecordPadEvery;
+
+/* What a loader lane publishes for its row's entry of one slab column.  `at` is the byte offset of the X row inside
+ * the LDS tile, computed once by the loader instead of by each of the KP consumer lanes; negative = no entry. */
+template <typename T> struct alignas(16) SpmmRecord {
+    T coef;
+    int at;
+};
+/* moved as ONE 16-byte LDS access (the compiler would split a plain struct copy into b64 + b32) */
+template <typename T> __device__ inline SpmmRecord<T> loadRecord(const SpmmRecord<T>* p)
+{
+    const Pack<uint32_t, 4> raw = loadPack<false, uint32_t, 4>(reinterpret_cast<const uint32_t*>(p));
+    SpmmRecord<T> out;
+    __builtin_memcpy(&out, &raw, sizeof(out));
+    return out;
+}
+template <typename T> __device__ inline void storeRecord(SpmmRecord<T>* p, T coef, int at)
+{
+    SpmmRecord<T> rec = {};
+    rec.coef = coef;
+    rec.at = at;
+    Pack<uint32_t, 4> raw;
+    __builtin_memcpy(&raw, &rec, sizeof(raw));
+    storePack<uint32_t, 4>(reinterpret_cast<uint32_t*>(p), raw);
+}
+
 template <typename T, int KP, int VEC, int UNROLL, bool FROM_LDS>
 __device__ inline void spmmAccumulate(const SpmmArgs<T>& a, int lane, int myLen, int groupLongest,
                                       const T* __restrict__ vals, const int* __restrict__ idxs,
-                                      const T* __restrict__ tile, int tileFirst, T (&sum)[KP][VEC])
+                                      const T* __restrict__ tile, int tileFirst, T (&sum)[KP][VEC],
+                                      SpmmRecord<T>* records = nullptr)
 {
     constexpr int TILE_LD = KP * VEC;
+    /* CHUNK rows of the team at a time: CHUNK X-row reads in flight per lane */
+    constexpr int CHUNK = KP < 4 ? KP : 4;
     const int team = lane / KP;
     const int rhs0 = (lane % KP) * VEC;
     const int rhsSafe = rhs0 < a.count ? rhs0 : 0; /* lanes beyond `count` read a valid slice, result discarded */
-    const T* __restrict__ Xsafe = a.X + rhsSafe;
 
     auto fetch = [&](int kBase, T* coef, int* col) {
 #pragma unroll
@@ -89,51 +124,76 @@ __device__ inline void spmmAccumulate(const SpmmArgs<T>& a, int lane, int myLen,
             }
         }
     };
-    auto consume = [&](const T* coefMine, const int* colMine) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            /* CHUNK rows of the team at a time: CHUNK X-row reads in flight per lane */
-            constexpr int CHUNK = KP < 4 ? KP : 4;
-#pragma unroll
-            for (int i0 = 0; i0 < KP; i0 += CHUNK) {
-                T coef[CHUNK];
-                int col[CHUNK];
-                Pack<T, VEC> xv[CHUNK];
-#pragma unroll
-                for (int i = 0; i < CHUNK; ++i) {
-                    const int src = team * KP + i0 + i;
-                    coef[i] = laneFrom(coefMine[u], src);
-                    col[i] = laneFrom(colMine[u], src);
-                }
-#pragma unroll
-                for (int i = 0; i < CHUNK; ++i) {
-                    /* no branch: inactive slots read a valid row and are discarded below */
-                    if constexpr (FROM_LDS)
-                        xv[i] = loadPack<false, T, VEC>(tile + (col[i] >= 0 ? col[i] - tileFirst : 0) * TILE_LD + rhsSafe);
-                    else
-                        xv[i] = loadPack<false, T, VEC>(Xsafe + (long long)(col[i] >= 0 ? col[i] : 0) * a.ldX);
-                }
-#pragma unroll
-                for (int i = 0; i < CHUNK; ++i)
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        sum[i0 + i][e] = pick(col[i] >= 0, mulAdd(coef[i], xv[i].v[e], sum[i0 + i][e]), sum[i0 + i][e]);
-                /* keep the scheduler from hoisting every chunk's shuffles and reads to the top:
-                 * that costs registers (occupancy), not latency -- other wavefronts cover it */
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
 
     T coefMine[UNROLL];
     int colMine[UNROLL];
     if constexpr (FROM_LDS) {
+        static_assert(KP == kRecordPadEvery, "record padding assumes one pad slot per team");
+        static_assert(UNROLL % kSpmmStage == 0, "a trip is a whole number of stages");
+        const unsigned char* const myTile = reinterpret_cast<const unsigned char*>(tile) + rhsSafe * sizeof(T);
+        const SpmmRecord<T>* const teamRecords = records + team * (KP + 1);
+        SpmmRecord<T>* const myRecord = records + lane + lane / kRecordPadEvery;
+        /* ALL_PRESENT: every row of the wavefront has an entry in these slab columns (always, for uniform rows):
+         * no per-entry test, 16 fused multiply-adds + 8 address adds per lane and column.  Otherwise absent
+         * entries (at < 0) read tile row 0 and their product is discarded. */
+        auto consume = [&](auto allPresent) {
+            constexpr bool ALL_PRESENT = decltype(allPresent)::value;
+            /* all KP rows of the team at once: LDS bounds the occupancy here (3 wavefronts per SIMD), so the
+             * registers for KP reads in flight are free */
+            constexpr int CHUNK = KP;
+#pragma unroll
+            for (int u = 0; u < kSpmmStage; ++u) {
+#pragma unroll
+                for (int i0 = 0; i0 < KP; i0 += CHUNK) {
+                    SpmmRecord<T> rec[CHUNK];
+                    Pack<T, VEC> xv[CHUNK];
+#pragma unroll
+                    for (int i = 0; i < CHUNK; ++i) /* one 16-byte LDS read, the same address for the lanes of a team */
+                        rec[i] = loadRecord(teamRecords + u * kRecordsPerColumn + i0 + i);
+#pragma unroll
+                    for (int i = 0; i < CHUNK; ++i) {
+                        const int at = ALL_PRESENT ? rec[i].at : (rec[i].at >= 0 ? rec[i].at : 0);
+                        xv[i] = loadPack<false, T, VEC>(reinterpret_cast<const T*>(myTile + at));
+                    }
+#pragma unroll
+                    for (int i = 0; i < CHUNK; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const T next = mulAdd(rec[i].coef, xv[i].v[e], sum[i0 + i][e]);
+                            sum[i0 + i][e] = ALL_PRESENT ? next : pick(rec[i].at >= 0, next, sum[i0 + i][e]);
+                        }
+                    /* keep the scheduler from hoisting every chunk's reads to the top: that costs registers
+                     * (occupancy), not latency -- other wavefronts cover it */
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        const int groupShortest = waveMin(myLen);
         T coefNext[UNROLL];
         int colNext[UNROLL];
         fetch(0, coefMine, colMine);
         for (int kBase = 0; kBase < groupLongest; kBase += UNROLL) {
+            /* (coef, col) of the next UNROLL columns requested now: 2*UNROLL loads per lane stay in flight (vmcnt)
+             * while this trip runs on LDS (lgkmcnt).  With the 3 wavefronts per SIMD the tile leaves room for,
+             * this depth is what keeps enough bytes in flight to cover the HBM latency. */
             fetch(kBase + UNROLL, coefNext, colNext);
-            consume(coefMine, colMine);
+#pragma unroll
+            for (int s0 = 0; s0 < UNROLL; s0 += kSpmmStage) {
+                if (kBase + s0 < groupLongest) { /* wavefront-uniform */
+                    /* publish kSpmmStage columns to the wavefront's own record slots; a wavefront's LDS operations
+                     * execute in order, the barriers only stop the compiler from reordering across them */
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int u = 0; u < kSpmmStage; ++u)
+                        storeRecord(myRecord + u * kRecordsPerColumn, coefMine[s0 + u],
+                                    colMine[s0 + u] >= 0 ? (colMine[s0 + u] - tileFirst) * (int)(TILE_LD * sizeof(T)) : -1);
+                    __builtin_amdgcn_wave_barrier();
+                    if (kBase + s0 + kSpmmStage <= groupShortest) /* wavefront-uniform */
+                        consume(std::true_type{});
+                    else
+                        consume(std::false_type{});
+                }
+            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 coefMine[u] = coefNext[u];
@@ -141,9 +201,33 @@ __device__ inline void spmmAccumulate(const SpmmArgs<T>& a, int lane, int myLen,
             }
         }
     } else {
+        const T* __restrict__ Xsafe = a.X + rhsSafe;
         for (int kBase = 0; kBase < groupLongest; kBase += UNROLL) {
             fetch(kBase, coefMine, colMine);
-            consume(coefMine, colMine);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+                for (int i0 = 0; i0 < KP; i0 += CHUNK) {
+                    T coef[CHUNK];
+                    int col[CHUNK];
+                    Pack<T, VEC> xv[CHUNK];
+#pragma unroll
+                    for (int i = 0; i < CHUNK; ++i) {
+                        const int src = team * KP + i0 + i;
+                        coef[i] = laneFrom(coefMine[u], src);
+                        col[i] = laneFrom(colMine[u], src);
+                    }
+#pragma unroll
+                    for (int i = 0; i < CHUNK; ++i) /* no branch: absent entries read row 0 and are discarded below */
+                        xv[i] = loadPack<false, T, VEC>(Xsafe + (long long)(col[i] >= 0 ? col[i] : 0) * a.ldX);
+#pragma unroll
+                    for (int i = 0; i < CHUNK; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e)
+                            sum[i0 + i][e] = pick(col[i] >= 0, mulAdd(coef[i], xv[i].v[e], sum[i0 + i][e]), sum[i0 + i][e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
 }
@@ -251,13 +335,14 @@ __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T>
         blockWindow(lo, hi);
         const bool worthScanning = hi < lo || (long long)hi - lo < a.tileRows; /* workgroup-uniform */
         if (worthScanning) {
-            for (int k0 = 1; k0 < myLen; k0 += 8) {
-                int c[8];
+            constexpr int SCAN = 16; /* independent loads per trip: the scan is a chain of memory latencies */
+            for (int k0 = 1; k0 < myLen; k0 += SCAN) {
+                int c[SCAN];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < SCAN; ++u)
                     c[u] = k0 + u < myLen ? idxs[(long long)(k0 + u) * a.hackSize] - a.baseIndex : -1;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < SCAN; ++u) {
                     if (c[u] >= 0) {
                         lo = c[u] < lo ? c[u] : lo;
                         hi = c[u] > hi ? c[u] : hi;
@@ -269,19 +354,34 @@ __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T>
         const bool useTile = worthScanning && hi >= lo && (long long)hi - lo < a.tileRows; /* workgroup-uniform */
         if (useTile) {
             const int window = hi - lo + 1;
-            /* KP lanes copy one X row, VEC elements (16 bytes) each */
-            for (int i = threadIdx.x; i < window * KP; i += kSpmmThreads) {
-                const int r = i / KP, piece = i % KP;
-                if (piece * VEC < a.count)
-                    storePack<T, VEC>(tile + r * TILE_LD + piece * VEC,
-                                      loadPack<false, T, VEC>(a.X + (long long)(lo + r) * a.ldX + piece * VEC));
+            /* KP lanes copy one X row, VEC elements (16 bytes) each; FILL loads per lane in flight */
+            constexpr int FILL = 4;
+            const int pieces = window * KP;
+            for (int i0 = threadIdx.x; i0 < pieces; i0 += FILL * kSpmmThreads) {
+                Pack<T, VEC> part[FILL];
+#pragma unroll
+                for (int f = 0; f < FILL; ++f) {
+                    const int i = i0 + f * kSpmmThreads;
+                    const int r = i / KP, piece = i % KP;
+                    if (i < pieces && piece * VEC < a.count)
+                        part[f] = loadPack<false, T, VEC>(a.X + (long long)(lo + r) * a.ldX + piece * VEC);
+                }
+#pragma unroll
+                for (int f = 0; f < FILL; ++f) {
+                    const int i = i0 + f * kSpmmThreads;
+                    const int r = i / KP, piece = i % KP;
+                    if (i < pieces && piece * VEC < a.count)
+                        storePack<T, VEC>(tile + r * TILE_LD + piece * VEC, part[f]);
+                }
             }
         }
         __syncthreads();
+        /* per-wavefront record slots behind the tile */
+        SpmmRecord<T>* records = reinterpret_cast<SpmmRecord<T>*>(spmmLds + kSpmmTileBytes) + (threadIdx.x >> 6) * (kSpmmStage * kRecordsPerColumn);
         if (useTile)
-            spmmAccumulate<T, KP, VEC, UNROLL, true>(a, lane, myLen, groupLongest, vals, idxs, tile, lo, sum);
-        else
-            spmmAccumulate<T, KP, VEC, UNROLL, false>(a, lane, myLen, groupLongest, vals, idxs, tile, 0, sum);
+            spmmAccumulate<T, KP, VEC, UNROLL, true>(a, lane, myLen, groupLongest, vals, idxs, tile, lo, sum, records);
+        else /* window too wide: X through L1/L2, the plain kernel's trip width */
+            spmmAccumulate<T, KP, VEC, (UNROLL < 2 ? UNROLL : 2), false>(a, lane, myLen, groupLongest, vals, idxs, tile, 0, sum);
         if (groupRow0 >= a.rows)
             return;
     } else {
@@ -290,7 +390,325 @@ __global__ __launch_bounds__(kSpmmThreads) void hellSpmmKernel(const SpmmArgs<T>
     spmmStore<T, KP, VEC>(a, lane, groupRow0, sum);
 }
 
-constexpr int kSpmmTileBytes = 48 * 1024; /* three workgroups per CU keep their tiles in the 160 KiB LDS */
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Strip-loading tiled kernel: hackSize a multiple of 32, up to 16 right-hand sides as 8 lanes x 2.
+ *
+ * The LDS tile leaves room for 3 wavefronts per SIMD only, so what bounds the kernel is the number of bytes each
+ * wavefront keeps in flight.  One-row-per-lane loads move 4 (index) or 8 (coefficient) bytes per lane; here every
+ * load is 16 bytes per lane: a wavefront's 64 rows are two halves of 32 rows, each inside one hack, and
+ *   index role        lane l reads rows 4q..4q+3 (q = l%8) of half (l/8)%2 in slab column k0 + l/16: one
+ *                     instruction covers 4 slab columns of the 64 rows;
+ *   coefficient role  the same with 16/sizeof(T) rows per lane: 2 (double) or 1 (float) instructions per 4 columns.
+ * A stage is 4 slab columns.  The loader lanes publish it to the wavefront's own LDS staging area -- the byte
+ * offset of the X row inside the tile, computed once, or -1 for "no entry", and the coefficient -- and the teams
+ * read their 8 rows' values back with 16-byte LDS reads (same address for the 8 lanes of a team).  A trip is
+ * TRIP stages; the loads of the next trip are issued before the current one is consumed and stay in flight while
+ * it runs on LDS.  The window scan of the prologue uses the same 16-byte index loads, 8 per lane in flight.
+ * Per (row, rhs) the products are still added in ascending k.
+ */
+constexpr int kStageCols = 4;
+constexpr int kStripTileBytes = 40 * 1024; /* + 4 staging areas of 3 KiB (double) = 52 KiB: three workgroups per CU */
+
+template <typename T> struct alignas(16) SpmmStage {
+    int at[kStageCols][kWave];
+    T coef[kStageCols][kWave];
+};
+
+__device__ inline void waveSync()
+{
+    /* a wavefront's LDS operations execute in order; this only pins the compiler's order of the accesses */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+/* amdgpu_waves_per_eu(3): the LDS footprint admits 3 wavefronts per SIMD; tell the register allocator to stay
+ * within the matching 168 VGPRs instead of trading occupancy for scheduling freedom */
+template <typename T, int TRIP>
+__global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void hellSpmmStripKernel(const SpmmArgs<T> a)
+{
+    constexpr int KP = 8, VEC = 2, TILE_LD = KP * VEC;
+    constexpr int ROW_BYTES = TILE_LD * (int)sizeof(T);
+    constexpr int CR = 16 / (int)sizeof(T);                     /* rows per coefficient load */
+    constexpr int COEF_LOADS = kStageCols * (int)sizeof(T) / 16; /* per stage */
+    constexpr int COLS_PER_COEF_LOAD = kStageCols / COEF_LOADS;
+    constexpr int LANES_PER_HALF_COL = 32 / CR;
+    constexpr int WAVES = kSpmmThreads / kWave;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char spmmLds[];
+    __shared__ int waveLo[WAVES], waveHi[WAVES];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const long long groupRow0 = ((long long)blockIdx.x * WAVES + wave) * kWave;
+    T* const tile = reinterpret_cast<T*>(spmmLds);
+    SpmmStage<T>* const stage = reinterpret_cast<SpmmStage<T>*>(spmmLds + kStripTileBytes) + wave;
+    const unsigned hs = (unsigned)a.hackSize;
+
+    /* ---- index role ---- */
+    const int iCol = lane >> 4, iHalf = (lane >> 3) & 1, iQ = lane & 7;
+    const long long iRow0 = groupRow0 + 32 * iHalf + 4 * iQ;
+    int iLen[4] = {0, 0, 0, 0};
+    const int* __restrict__ iBase = a.rP;
+    if (iRow0 < a.rows) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (iRow0 + j < a.rows)
+                iLen[j] = a.rS[iRow0 + j];
+        const unsigned hack = (unsigned)iRow0 / hs;
+        iBase += (long long)a.hackOffsets[hack] + ((unsigned)iRow0 - hack * hs);
+    }
+    int iLenMax = iLen[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        iLenMax = iLen[j] > iLenMax ? iLen[j] : iLenMax;
+    /* ---- coefficient role ---- */
+    const int cCol = lane / (2 * LANES_PER_HALF_COL), cHalf = (lane / LANES_PER_HALF_COL) & 1, cQ = lane % LANES_PER_HALF_COL;
+    const long long cRow0 = groupRow0 + 32 * cHalf + CR * cQ;
+    int cLenMax = 0;
+    const T* __restrict__ cBase = a.cM;
+    if (cRow0 < a.rows) {
+#pragma unroll
+        for (int j = 0; j < CR; ++j)
+            if (cRow0 + j < a.rows) {
+                const int len = a.rS[cRow0 + j];
+                cLenMax = len > cLenMax ? len : cLenMax;
+            }
+        const unsigned hack = (unsigned)cRow0 / hs;
+        cBase += (long long)a.hackOffsets[hack] + ((unsigned)cRow0 - hack * hs);
+    }
+    const int groupLongest = waveMax(iLenMax);
+
+    /* ---- prologue: the window of X rows the workgroup's 256 matrix rows touch ---- */
+    auto blockWindow = [&](int& lo, int& hi) {
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) {
+            const int olo = laneXor(lo, m), ohi = laneXor(hi, m);
+            lo = olo < lo ? olo : lo;
+            hi = ohi > hi ? ohi : hi;
+        }
+        __syncthreads(); /* previous use of waveLo/waveHi is over */
+        if (lane == 0) {
+            waveLo[wave] = lo;
+            waveHi[wave] = hi;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            lo = waveLo[w] < lo ? waveLo[w] : lo;
+            hi = waveHi[w] > hi ? waveHi[w] : hi;
+        }
+    };
+    auto widen = [&](const Pack<int, 4>& c4, int k, int& lo, int& hi) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c4.v[j] - a.baseIndex;
+            if (k < iLen[j] && c >= 0) {
+                lo = c < lo ? c : lo;
+                hi = c > hi ? c : hi;
+            }
+        }
+    };
+    int lo = 0x7fffffff, hi = -1;
+    /* probe on the first stage only (one load): scattered matrices already span more than the tile there */
+    if (iCol < iLenMax)
+        widen(loadPack<false, int, 4>(iBase + (long long)iCol * hs), iCol, lo, hi);
+    blockWindow(lo, hi);
+    const bool worthScanning = hi < lo || (long long)hi - lo < a.tileRows; /* workgroup-uniform */
+    if (worthScanning) {
+        constexpr int SCAN = 8; /* 16-byte loads per lane in flight: 32 slab columns per trip */
+        for (int k0 = kStageCols; k0 < groupLongest; k0 += kStageCols * SCAN) {
+            Pack<int, 4> c4[SCAN];
+#pragma unroll
+            for (int u = 0; u < SCAN; ++u) {
+                const int k = k0 + kStageCols * u + iCol;
+                if (k < iLenMax)
+                    c4[u] = loadPack<false, int, 4>(iBase + (long long)k * hs);
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN; ++u) {
+                const int k = k0 + kStageCols * u + iCol;
+                if (k < iLenMax)
+                    widen(c4[u], k, lo, hi);
+            }
+        }
+        blockWindow(lo, hi);
+    }
+    const bool useTile = worthScanning && hi >= lo && (long long)hi - lo < a.tileRows; /* workgroup-uniform */
+    if (useTile) {
+        /* KP lanes copy one X row, VEC elements (16 bytes) each; FILL loads per lane in flight */
+        constexpr int FILL = 5;
+        const int pieces = (hi - lo + 1) * KP;
+        for (int i0 = threadIdx.x; i0 < pieces; i0 += FILL * kSpmmThreads) {
+            Pack<T, VEC> part[FILL];
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) {
+                const int i = i0 + f * kSpmmThreads;
+                const int r = i / KP, piece = i % KP;
+                if (i < pieces && piece * VEC < a.count)
+                    part[f] = loadPack<false, T, VEC>(a.X + (long long)(lo + r) * a.ldX + piece * VEC);
+            }
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) {
+                const int i = i0 + f * kSpmmThreads;
+                const int r = i / KP, piece = i % KP;
+                if (i < pieces && piece * VEC < a.count)
+                    storePack<T, VEC>(tile + r * TILE_LD + piece * VEC, part[f]);
+            }
+        }
+    }
+    __syncthreads();
+
+    T sum[KP][VEC];
+#pragma unroll
+    for (int i = 0; i < KP; ++i)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            sum[i][e] = zeroOf<T>();
+
+    if (!useTile) {
+        /* window too wide for the tile: one row per lane, X through L1/L2 (the plain kernel's loop) */
+        const long long myRow = groupRow0 + lane;
+        int myLen = 0;
+        long long slab = 0;
+        if (myRow < a.rows) {
+            const unsigned hack = (unsigned)myRow / hs;
+            slab = (long long)a.hackOffsets[hack] + ((unsigned)myRow - hack * hs);
+            myLen = a.rS[myRow];
+        }
+        spmmAccumulate<T, KP, VEC, 2, false>(a, lane, myLen, groupLongest, a.cM + slab, a.rP + slab, nullptr, 0, sum);
+    } else {
+        const int team = lane / KP;
+        const int rhs0 = (lane % KP) * VEC;
+        const int rhsSafe = rhs0 < a.count ? rhs0 : 0; /* lanes beyond `count` read a valid slice, result discarded */
+        const unsigned char* const myTile = reinterpret_cast<const unsigned char*>(tile) + rhsSafe * sizeof(T);
+
+        struct Trip {
+            Pack<int, 4> idx[TRIP];
+            Pack<T, CR> coef[TRIP * COEF_LOADS];
+        };
+        auto loadTrip = [&](int k0, Trip& t) {
+#pragma unroll
+            for (int s = 0; s < TRIP; ++s) {
+                const int ki = k0 + kStageCols * s + iCol;
+                if (ki < iLenMax)
+                    t.idx[s] = loadPack<true, int, 4>(iBase + (long long)ki * hs);
+                else
+                    t.idx[s] = Pack<int, 4>{{0, 0, 0, 0}};
+#pragma unroll
+                for (int j = 0; j < COEF_LOADS; ++j) {
+                    const int kc = k0 + kStageCols * s + COLS_PER_COEF_LOAD * j + cCol;
+                    if (kc < cLenMax) {
+                        t.coef[s * COEF_LOADS + j] = loadPack<true, T, CR>(cBase + (long long)kc * hs);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < CR; ++e)
+                            t.coef[s * COEF_LOADS + j].v[e] = zeroOf<T>();
+                    }
+                }
+            }
+        };
+        /* wavefront-uniform: every row of the wavefront has an entry in every column of the trip */
+        auto allPresent = [&](const Trip& t, int k0) {
+            bool absent = false;
+#pragma unroll
+            for (int s = 0; s < TRIP; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    absent |= !(k0 + kStageCols * s + iCol < iLen[j] && t.idx[s].v[j] - a.baseIndex >= 0);
+            return __ballot(absent) == 0ull;
+        };
+        auto publish = [&](const Trip& t, int s, int k0) {
+            const int ki = k0 + kStageCols * s + iCol;
+            Pack<int, 4> at4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = t.idx[s].v[j] - a.baseIndex;
+                at4.v[j] = ki < iLen[j] && c >= 0 ? (c - lo) * ROW_BYTES : -1;
+            }
+            storePack<int, 4>(&stage->at[iCol][32 * iHalf + 4 * iQ], at4);
+#pragma unroll
+            for (int j = 0; j < COEF_LOADS; ++j)
+                storePack<T, CR>(&stage->coef[COLS_PER_COEF_LOAD * j + cCol][32 * cHalf + CR * cQ], t.coef[s * COEF_LOADS + j]);
+        };
+        auto consume = [&](auto allPresent) {
+            constexpr bool ALL_PRESENT = decltype(allPresent)::value;
+#pragma unroll
+            for (int c = 0; c < kStageCols; ++c) {
+#pragma unroll
+                for (int i0 = 0; i0 < KP; i0 += 4) { /* 4 rows of the team at a time */
+                    T coef[4];
+                    Pack<T, VEC> xv[4];
+                    const Pack<int, 4> at = loadPack<false, int, 4>(&stage->at[c][KP * team + i0]);
+#pragma unroll
+                    for (int j0 = 0; j0 < 4; j0 += CR) {
+                        const Pack<T, CR> part = loadPack<false, T, CR>(&stage->coef[c][KP * team + i0 + j0]);
+#pragma unroll
+                        for (int j = 0; j < CR; ++j)
+                            coef[j0 + j] = part.v[j];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        xv[i] = loadPack<false, T, VEC>(reinterpret_cast<const T*>(myTile + (ALL_PRESENT || at.v[i] >= 0 ? at.v[i] : 0)));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const T next = mulAdd(coef[i], xv[i].v[e], sum[i0 + i][e]);
+                            sum[i0 + i][e] = ALL_PRESENT ? next : pick(at.v[i] >= 0, next, sum[i0 + i][e]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0); /* keep the reads of later chunks from being hoisted: registers */
+                }
+            }
+        };
+
+        auto runTrip = [&](const Trip& t, int k0, auto mode) {
+#pragma unroll
+            for (int s = 0; s < TRIP; ++s) {
+                if (k0 + kStageCols * s < groupLongest) { /* wavefront-uniform */
+                    waveSync();
+                    publish(t, s, k0);
+                    waveSync();
+                    consume(mode);
+                }
+            }
+        };
+        /* Two loops rather than a per-stage choice: absent entries only appear in the last columns of ragged rows,
+         * and one loop body per mode keeps the 32 running sums in one set of registers. */
+        constexpr int STEP = kStageCols * TRIP;
+        Trip cur, next;
+        loadTrip(0, cur);
+        loadTrip(STEP, next);
+        int k0 = 0;
+#pragma clang loop unroll(disable)
+        while (k0 < groupLongest && allPresent(cur, k0)) {
+            runTrip(cur, k0, std::true_type{});
+            cur = next;
+            k0 += STEP;
+            loadTrip(k0 + STEP, next); /* in flight (vmcnt) while the next trip runs on LDS (lgkmcnt) */
+        }
+#pragma clang loop unroll(disable)
+        while (k0 < groupLongest) {
+            runTrip(cur, k0, std::false_type{});
+            cur = next;
+            k0 += STEP;
+            loadTrip(k0 + STEP, next);
+        }
+    }
+    if (groupRow0 >= a.rows)
+        return;
+    spmmStore<T, KP, VEC>(a, lane, groupRow0, sum);
+}
+
+template <typename T, int TRIP> static void launchSpmmStrips(hipStream_t stream, const SpmmArgs<T>& in)
+{
+    SpmmArgs<T> a = in;
+    const long long groups = ((long long)a.rows + kWave - 1) / kWave;
+    const unsigned blocks = (unsigned)((groups + kSpmmThreads / kWave - 1) / (kSpmmThreads / kWave));
+    a.tileRows = kStripTileBytes / (16 * (int)sizeof(T));
+    const size_t lds = kStripTileBytes + (kSpmmThreads / kWave) * sizeof(SpmmStage<T>);
+    hipLaunchKernelGGL((hellSpmmStripKernel<T, TRIP>), dim3(blocks), dim3(kSpmmThreads), lds, stream, a);
+}
 
 template <typename T, int KP, int VEC, int UNROLL, bool TILED = false>
 static void launchSpmm(hipStream_t stream, const SpmmArgs<T>& in)
@@ -299,8 +717,8 @@ static void launchSpmm(hipStream_t stream, const SpmmArgs<T>& in)
     const long long groups = ((long long)a.rows + kWave - 1) / kWave;
     const unsigned blocks = (unsigned)((groups + kSpmmThreads / kWave - 1) / (kSpmmThreads / kWave));
     a.tileRows = TILED ? kSpmmTileBytes / (KP * VEC * (int)sizeof(T)) : 0;
-    hipLaunchKernelGGL((hellSpmmKernel<T, KP, VEC, UNROLL, TILED>), dim3(blocks), dim3(kSpmmThreads),
-                       TILED ? kSpmmTileBytes : 0, stream, a);
+    const size_t lds = TILED ? kSpmmTileBytes + (kSpmmThreads / kWave) * kSpmmStage * kRecordsPerColumn * sizeof(SpmmRecord<T>) : 0;
+    hipLaunchKernelGGL((hellSpmmKernel<T, KP, VEC, UNROLL, TILED>), dim3(blocks), dim3(kSpmmThreads), lds, stream, a);
 }
 
 template <typename T>
@@ -336,19 +754,25 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
         a.ldYZ = ldYZ;
         a.tileRows = 0;
         const bool pairs = pairsOk && a.count % 2 == 0;
+        /* 16-byte loads of whole 32-row half columns */
+        const bool strips = pairs && hackSize % 32 == 0 && (uintptr_t)cM % 16 == 0 && (uintptr_t)rP % 16 == 0;
         const char* ev = getenv("SPGPU_SPMM_VARIANT"); /* experiments */
         const int variant = ev && *ev ? atoi(ev) : 0;
         if (a.count > 8) {
             if (pairs && variant == 1)
                 launchSpmm<T, 8, 2, 2>(stream, a);          /* plain: X rows through L1 */
             else if (pairs && variant == 2)
-                launchSpmm<T, 8, 2, 4, true>(stream, a);    /* tiled, 4 slab columns per stage */
+                launchSpmm<T, 8, 2, 8, true>(stream, a);    /* tiled, 8 slab columns per trip */
             else if (pairs && variant == 3)
                 launchSpmm<T, 8, 2, 4>(stream, a);
             else if (variant == 4)
                 launchSpmm<T, 16, 1, 2>(stream, a);
-            else if (pairs)
-                launchSpmm<T, 8, 2, 2, true>(stream, a);    /* default: X window staged in LDS when it fits */
+            else if (pairs && variant == 5)
+                launchSpmm<T, 8, 2, 2, true>(stream, a);    /* tiled, 2 slab columns per trip */
+            else if (pairs && (variant == 6 || !strips))
+                launchSpmm<T, 8, 2, 4, true>(stream, a);    /* tiled, one row per loader lane */
+            else if (strips)
+                launchSpmmStrips<T, 2>(stream, a);          /* default: X window in LDS when it fits, 16-byte loads */
             else
                 launchSpmm<T, 16, 1, 2>(stream, a);
         } else if (a.count > 4) {

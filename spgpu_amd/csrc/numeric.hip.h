@@ -154,4 +154,14 @@ __device__ inline int waveMax(int v)
     return v;
 }
 
+__device__ inline int waveMin(int v)
+{
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+        const int other = laneXor(v, m);
+        v = other < v ? other : v;
+    }
+    return v;
+}
+
 } // namespace spgpu

@@ -117,3 +117,35 @@ def test_own_rest_column_split_reproduces_the_block(gpu, pattern):
     # and the whole block against the oracle, bit for bit
     sub = synth.hell_rows_to_host(block, 0, rows)
     assert a.tobytes() == O.hell_spmm(sub, X.cpu().numpy(), None, 1.0, 0.0).tobytes()
+
+
+@pytest.mark.parametrize("letter,hs,count,base", [("D", 32, 16, 0), ("D", 64, 12, 1), ("D", 96, 16, 1), ("S", 32, 16, 1),
+                                                  ("S", 64, 10, 0), ("D", 32, 32, 0)])
+def test_spmm_window_tile_with_ragged_rows(gpu, letter, hs, count, base):
+    """The LDS-tile path (columns of a workgroup's 256 rows inside a narrow window) on what it has to get right:
+    rows of different lengths including empty ones, a last wavefront and a last hack that are partly filled,
+    one-based indices, fewer than 16 right-hand sides, hack sizes 32/64/96 -- bit for bit against the oracle."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    rng = np.random.default_rng(hs + count)
+    rows = 1000 + hs // 2 + 5                      # not a multiple of 4, 32, 64 or the hack size
+    lengths = rng.integers(0, 41, size=rows)
+    lengths[rng.integers(0, rows, size=40)] = 0
+    lengths[:64] = 24                              # one wavefront with uniform rows: the unchecked loop only
+    r = np.repeat(np.arange(rows), lengths)
+    c = np.concatenate([np.sort(rng.choice(np.arange(max(0, i - 30), min(rows, i + 31)), size=n, replace=False))
+                        for i, n in enumerate(lengths)]) if r.size else np.zeros(0, dtype=np.int64)
+    v = synth.values_for(letter, 3, r.size)
+    hell = formats.ell_to_hell(formats.coo_to_ell(rows, r, c, v, ell_base=base), hs)
+    X = synth.values_for(letter, 4, rows * count).reshape(rows, count)
+    Y = synth.values_for(letter, 5, rows * count).reshape(rows, count)
+    mat = formats.DeviceHell(hell)
+    dX, dY = formats.to_device(X), formats.to_device(Y)
+    for beta in (0.0, 0.5):
+        dZ = torch.full_like(dY, float("nan"))
+        capi.hellspmm[letter](gpu, _p(dZ), _p(dY), capi.scalar(letter, -1.5), _p(mat.cM), _p(mat.rP), mat.hack_size,
+                              _p(mat.hack_offsets), _p(mat.rS), None, 0, mat.rows, _p(dX), capi.scalar(letter, beta),
+                              mat.base, count, count, count)
+        torch.cuda.synchronize()
+        want = O.hell_spmm(hell, X, Y if beta != 0 else None, -1.5, beta)
+        assert dZ.cpu().numpy().tobytes() == want.tobytes()
