@@ -31,7 +31,11 @@ $(LIBDIR)/libspgpu.so: $(OBJS)
 
 $(BUILD)/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p $(BUILD)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) $(FLAGS_$*) -c $< -o $@
+
+# hell_spmm: the SLP vectorizer pairs fp32 sums of DIFFERENT rows into v_pk_fma_f32 and shuffles operands to feed
+# them; that costs ~40 VGPRs (and scratch in the strip kernel) for flops an HBM-bound kernel does not need.
+FLAGS_hell_spmm := -fno-slp-vectorize
 
 # Host C/C++ goes through hipcc as well (plain clang for these files): one toolchain.
 $(BUILD)/%.c.o: $(CSRC)/%.c $(HDRS)

@@ -23,6 +23,12 @@
  * Per (row, rhs) the products are added in ascending k.  More than 16
  * right-hand sides run as passes of 16 (the matrix is re-read per pass).
  *
+ * This describes hellSpmmKernel (any hackSize, any rhs count).  The default for
+ * hackSize % 32 == 0 and an even rhs count > 8 is hellSpmmStripKernel further
+ * down: same teams and summation order, but 16-byte loads of whole half-columns,
+ * the X window of a workgroup in LDS, and (offset, coefficient) handed from the
+ * loader lanes to the teams through LDS instead of lane shuffles.
+ *
  * Roofline: HBM.  Algorithmic bytes: the matrix once, nnz*(sizeof(T)+4) +
  * rows*4 + hacks*4, plus count * (cols + rows*(1+[beta!=0])) * sizeof(T).
  */
@@ -510,14 +516,28 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
         }
     };
     int lo = 0x7fffffff, hi = -1;
-    /* probe on the first stage only (one load): scattered matrices already span more than the tile there */
-    if (iCol < iLenMax)
-        widen(loadPack<false, int, 4>(iBase + (long long)iCol * hs), iCol, lo, hi);
+    /* The indices of the first HEAD*4 slab columns are requested at once and stay in registers: the accumulation
+     * below takes them from there instead of reading them a second time.  The first load alone decides (probe)
+     * whether the rest is looked at: scattered matrices already span more than the tile in 4 columns. */
+    constexpr int HEAD = 8;
+    Pack<int, 4> head[HEAD];
+#pragma unroll
+    for (int u = 0; u < HEAD; ++u) {
+        const int k = kStageCols * u + iCol;
+        if (k < iLenMax)
+            head[u] = loadPack<false, int, 4>(iBase + (long long)k * hs);
+        else
+            head[u] = Pack<int, 4>{{0, 0, 0, 0}};
+    }
+    widen(head[0], iCol, lo, hi);
     blockWindow(lo, hi);
     const bool worthScanning = hi < lo || (long long)hi - lo < a.tileRows; /* workgroup-uniform */
     if (worthScanning) {
+#pragma unroll
+        for (int u = 1; u < HEAD; ++u)
+            widen(head[u], kStageCols * u + iCol, lo, hi);
         constexpr int SCAN = 8; /* 16-byte loads per lane in flight: 32 slab columns per trip */
-        for (int k0 = kStageCols; k0 < groupLongest; k0 += kStageCols * SCAN) {
+        for (int k0 = kStageCols * HEAD; k0 < groupLongest; k0 += kStageCols * SCAN) {
             Pack<int, 4> c4[SCAN];
 #pragma unroll
             for (int u = 0; u < SCAN; ++u) {
@@ -591,10 +611,16 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
 #pragma unroll
             for (int s = 0; s < TRIP; ++s) {
                 const int ki = k0 + kStageCols * s + iCol;
-                if (ki < iLenMax)
+                if (k0 + kStageCols * s < kStageCols * HEAD) { /* uniform: still in the registers of the prologue */
+                    t.idx[s] = head[0];
+#pragma unroll
+                    for (int u = 0; u + 1 < HEAD; ++u)
+                        head[u] = head[u + 1];
+                } else if (ki < iLenMax) {
                     t.idx[s] = loadPack<true, int, 4>(iBase + (long long)ki * hs);
-                else
+                } else {
                     t.idx[s] = Pack<int, 4>{{0, 0, 0, 0}};
+                }
 #pragma unroll
                 for (int j = 0; j < COEF_LOADS; ++j) {
                     const int kc = k0 + kStageCols * s + COLS_PER_COEF_LOAD * j + cCol;
