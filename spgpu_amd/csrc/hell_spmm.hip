@@ -441,9 +441,15 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
     constexpr int COLS_PER_COEF_LOAD = kStageCols / COEF_LOADS;
     constexpr int LANES_PER_HALF_COL = 32 / CR;
     constexpr int WAVES = kSpmmThreads / kWave;
+    /* Tile layout.  A team reads one whole X row (ROW_BYTES) per instruction, and the LDS serves 256 bytes (64 banks)
+     * per pass: rows at a distance of 8 -- what neighbouring teams read in a banded matrix -- would share banks if
+     * row r simply sat at r*ROW_BYTES.  Inside each 256-byte line the rows are therefore permuted by r>>3
+     * (measured: SQ_LDS_BANK_CONFLICT was 32 % of the LDS cycles without it). */
+    constexpr int ROWS_PER_LINE = 256 / ROW_BYTES;
+    auto tileOffset = [](int r) { return (r / ROWS_PER_LINE) * 256 + ((r ^ (r >> 3)) & (ROWS_PER_LINE - 1)) * ROW_BYTES; };
 
     extern __shared__ __attribute__((aligned(16))) unsigned char spmmLds[];
-    __shared__ int waveLo[WAVES], waveHi[WAVES];
+    __shared__ int waveLo[WAVES], waveHi[WAVES], waveLongest[WAVES];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const long long groupRow0 = ((long long)blockIdx.x * WAVES + wave) * kWave;
@@ -497,6 +503,7 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
         if (lane == 0) {
             waveLo[wave] = lo;
             waveHi[wave] = hi;
+            waveLongest[wave] = groupLongest;
         }
         __syncthreads();
 #pragma unroll
@@ -517,8 +524,7 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
     };
     int lo = 0x7fffffff, hi = -1;
     /* The indices of the first HEAD*4 slab columns are requested at once and stay in registers: the accumulation
-     * below takes them from there instead of reading them a second time.  The first load alone decides (probe)
-     * whether the rest is looked at: scattered matrices already span more than the tile in 4 columns. */
+     * below takes them from there instead of reading them a second time. */
     constexpr int HEAD = 8;
     Pack<int, 4> head[HEAD];
 #pragma unroll
@@ -529,13 +535,17 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
         else
             head[u] = Pack<int, 4>{{0, 0, 0, 0}};
     }
-    widen(head[0], iCol, lo, hi);
-    blockWindow(lo, hi);
-    const bool worthScanning = hi < lo || (long long)hi - lo < a.tileRows; /* workgroup-uniform */
-    if (worthScanning) {
 #pragma unroll
-        for (int u = 1; u < HEAD; ++u)
-            widen(head[u], kStageCols * u + iCol, lo, hi);
+    for (int u = 0; u < HEAD; ++u)
+        widen(head[u], kStageCols * u + iCol, lo, hi);
+    blockWindow(lo, hi);
+    int blockLongest = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w)
+        blockLongest = waveLongest[w] > blockLongest ? waveLongest[w] : blockLongest;
+    /* scattered matrices already span more than the tile here and skip the rest (workgroup-uniform) */
+    const bool fitsSoFar = hi < lo || (long long)hi - lo < a.tileRows;
+    if (fitsSoFar && blockLongest > kStageCols * HEAD) {
         constexpr int SCAN = 8; /* 16-byte loads per lane in flight: 32 slab columns per trip */
         for (int k0 = kStageCols * HEAD; k0 < groupLongest; k0 += kStageCols * SCAN) {
             Pack<int, 4> c4[SCAN];
@@ -554,8 +564,45 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
         }
         blockWindow(lo, hi);
     }
-    const bool useTile = worthScanning && hi >= lo && (long long)hi - lo < a.tileRows; /* workgroup-uniform */
+    const bool useTile = fitsSoFar && hi >= lo && (long long)hi - lo < a.tileRows; /* workgroup-uniform */
+
+    struct Trip {
+        Pack<int, 4> idx[TRIP];
+        Pack<T, CR> coef[TRIP * COEF_LOADS];
+    };
+    auto loadTrip = [&](int k0, Trip& t) {
+#pragma unroll
+        for (int s = 0; s < TRIP; ++s) {
+            const int ki = k0 + kStageCols * s + iCol;
+            if (k0 + kStageCols * s < kStageCols * HEAD) { /* uniform: still in the registers of the prologue */
+                t.idx[s] = head[0];
+#pragma unroll
+                for (int u = 0; u + 1 < HEAD; ++u)
+                    head[u] = head[u + 1];
+            } else if (ki < iLenMax) {
+                t.idx[s] = loadPack<true, int, 4>(iBase + (long long)ki * hs);
+            } else {
+                t.idx[s] = Pack<int, 4>{{0, 0, 0, 0}};
+            }
+#pragma unroll
+            for (int j = 0; j < COEF_LOADS; ++j) {
+                const int kc = k0 + kStageCols * s + COLS_PER_COEF_LOAD * j + cCol;
+                if (kc < cLenMax) {
+                    t.coef[s * COEF_LOADS + j] = loadPack<true, T, CR>(cBase + (long long)kc * hs);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CR; ++e)
+                        t.coef[s * COEF_LOADS + j].v[e] = zeroOf<T>();
+                }
+            }
+        }
+    };
+    constexpr int STEP = kStageCols * TRIP;
+    Trip cur, next;
     if (useTile) {
+        /* the first two trips' coefficients are requested before the tile is filled: one memory round trip for both */
+        loadTrip(0, cur);
+        loadTrip(STEP, next);
         /* KP lanes copy one X row, VEC elements (16 bytes) each; FILL loads per lane in flight */
         constexpr int FILL = 5;
         const int pieces = (hi - lo + 1) * KP;
@@ -573,7 +620,7 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
                 const int i = i0 + f * kSpmmThreads;
                 const int r = i / KP, piece = i % KP;
                 if (i < pieces && piece * VEC < a.count)
-                    storePack<T, VEC>(tile + r * TILE_LD + piece * VEC, part[f]);
+                    storePack<T, VEC>(reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(tile) + tileOffset(r)) + piece * VEC, part[f]);
             }
         }
     }
@@ -603,37 +650,6 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
         const int rhsSafe = rhs0 < a.count ? rhs0 : 0; /* lanes beyond `count` read a valid slice, result discarded */
         const unsigned char* const myTile = reinterpret_cast<const unsigned char*>(tile) + rhsSafe * sizeof(T);
 
-        struct Trip {
-            Pack<int, 4> idx[TRIP];
-            Pack<T, CR> coef[TRIP * COEF_LOADS];
-        };
-        auto loadTrip = [&](int k0, Trip& t) {
-#pragma unroll
-            for (int s = 0; s < TRIP; ++s) {
-                const int ki = k0 + kStageCols * s + iCol;
-                if (k0 + kStageCols * s < kStageCols * HEAD) { /* uniform: still in the registers of the prologue */
-                    t.idx[s] = head[0];
-#pragma unroll
-                    for (int u = 0; u + 1 < HEAD; ++u)
-                        head[u] = head[u + 1];
-                } else if (ki < iLenMax) {
-                    t.idx[s] = loadPack<true, int, 4>(iBase + (long long)ki * hs);
-                } else {
-                    t.idx[s] = Pack<int, 4>{{0, 0, 0, 0}};
-                }
-#pragma unroll
-                for (int j = 0; j < COEF_LOADS; ++j) {
-                    const int kc = k0 + kStageCols * s + COLS_PER_COEF_LOAD * j + cCol;
-                    if (kc < cLenMax) {
-                        t.coef[s * COEF_LOADS + j] = loadPack<true, T, CR>(cBase + (long long)kc * hs);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < CR; ++e)
-                            t.coef[s * COEF_LOADS + j].v[e] = zeroOf<T>();
-                    }
-                }
-            }
-        };
         /* wavefront-uniform: every row of the wavefront has an entry in every column of the trip */
         auto allPresent = [&](const Trip& t, int k0) {
             bool absent = false;
@@ -650,7 +666,7 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = t.idx[s].v[j] - a.baseIndex;
-                at4.v[j] = ki < iLen[j] && c >= 0 ? (c - lo) * ROW_BYTES : -1;
+                at4.v[j] = ki < iLen[j] && c >= 0 ? tileOffset(c - lo) : -1;
             }
             storePack<int, 4>(&stage->at[iCol][32 * iHalf + 4 * iQ], at4);
 #pragma unroll
@@ -701,10 +717,6 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
         };
         /* Two loops rather than a per-stage choice: absent entries only appear in the last columns of ragged rows,
          * and one loop body per mode keeps the 32 running sums in one set of registers. */
-        constexpr int STEP = kStageCols * TRIP;
-        Trip cur, next;
-        loadTrip(0, cur);
-        loadTrip(STEP, next);
         int k0 = 0;
 #pragma clang loop unroll(disable)
         while (k0 < groupLongest && allPresent(cur, k0)) {
