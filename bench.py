@@ -380,7 +380,7 @@ def run_spmm(args, rank, world):
                         rows_per_gpu=rows_local, rows_total=n_total, rhs=k, pattern=args.spmm_pattern,
                         parallelism=f"row partition x{world}, all-gather of X" + (", own/rest column split (overlap)" if split else "")),
             roofline=dict(bound="hbm", achieved=round(alg / t_compute * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                          frac=round(alg / t_compute * 1e-9 / HBM_PEAK_GBS, 4), traffic=None, kernel="hellSpmmKernel<double,16>",
+                          frac=round(alg / t_compute * 1e-9 / HBM_PEAK_GBS, 4), traffic=None, kernel="hellSpmmStripKernel<double,2>",
                           algorithmic_bytes_per_launch=alg, kernel_ms=round(t_compute * 1e3, 4)),
             spmm=dict(compute_only_ms=round(t_compute * 1e3, 4), allgather_only_ms=round(t_gather * 1e3, 4),
                       compute_only_gflops_total=round(flops_total / t_compute * 1e-9, 1),

@@ -18,6 +18,11 @@
  * handle->currentStream.  Z may alias Y exactly.  count <= 0 or rows <= 0 is a
  * no-op.  Per (row, rhs) the products are added in ascending k, i.e. in the
  * order of the reference's one-thread-per-row kernel.
+ *
+ * In-place sum: with Z == Y and beta == 1 (Z += alpha*A*X) the rows of A that
+ * have no entries (rS[i] == 0) are left untouched -- neither read nor written.
+ * The second product of a column-split row block (own columns first, the other
+ * ranks' columns after the all-gather) is almost entirely such rows.
  */
 #include "core.h"
 

@@ -894,6 +894,8 @@ void orc_isetscal(int first, int last, int base, int val, int* y)
         for (int i = 0; i < rows; ++i) {                                                                      \
             const size_t slot0 = (size_t)hackOffsets[i / hackSize] + (size_t)(i % hackSize);                  \
             const size_t out = (size_t)(rIdx ? rIdx[i] : i) * (size_t)ldYZ;                                   \
+            if (Y == Z && beta == (T)1 && rS[i] == 0)                                                         \
+                continue; /* in-place sum: rows without entries are left untouched (spmm.h) */                \
             for (int j = 0; j < count; ++j) {                                                                 \
                 T sum = P##_zero();                                                                           \
                 for (int k = 0; k < rS[i]; ++k) {                                                             \

@@ -247,10 +247,13 @@ __device__ inline void spmmStore(const SpmmArgs<T>& a, int lane, long long group
     if (rhs0 >= a.count)
         return;
     const bool hasBeta = isNotZero(a.beta);
+    /* Z += alpha*A*X in place (Y == Z, beta == 1): rows of A without entries keep their Z, unread and unwritten.
+     * This is what the "rest" product of a column-split row block is made of (spgpu_amd/sharded.py). */
+    const bool inPlaceSum = hasBeta && a.Y == a.Z && a.beta == T(1);
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
         const long long r = groupRow0 + team * KP + i;
-        if (r < a.rows) {
+        if (r < a.rows && !(inPlaceSum && a.rS[r] == 0)) {
             const long long outRow = a.rIdx ? a.rIdx[r] : r;
             const long long at = outRow * a.ldYZ + rhs0;
             Pack<T, VEC> out;

@@ -285,13 +285,15 @@ for _L in "SD":
     _f.argtypes = [ptr, ptr, SCALAR[_L], ptr, ptr, i32, ptr, ptr, ptr, i32, ptr, SCALAR[_L], i32, i32, i32, i32]
 
 
-def hell_spmm(hell, X, Y, alpha, beta, r_idx=None):
-    """Interleaved multivectors: X is [cols, count], Y/Z are [rows, count] (C-contiguous)."""
+def hell_spmm(hell, X, Y, alpha, beta, r_idx=None, in_place=False):
+    """Interleaved multivectors: X is [cols, count], Y/Z are [rows, count] (C-contiguous).
+    in_place: call with Z aliasing Y, as a caller accumulating into Z does (spmm.h: with beta == 1 rows without
+    entries are then left untouched)."""
     L = hell["letter"]
     X = np.ascontiguousarray(X, NP_DTYPE[L])
     count = X.shape[1]
     Z = np.zeros((hell["rows"], count), NP_DTYPE[L]) if Y is None else np.array(Y, NP_DTYPE[L], copy=True, order="C")
-    YY = None if Y is None else np.ascontiguousarray(Y, NP_DTYPE[L])
+    YY = None if Y is None else (Z if in_place else np.ascontiguousarray(Y, NP_DTYPE[L]))
     ri = None if r_idx is None else np.ascontiguousarray(r_idx, np.int32)
     getattr(orc, f"orc_{_LOW[L]}hellspmm")(_p(Z), _p(YY), scalar(L, alpha), _p(hell["values"]), _p(hell["indices"]),
                                            hell["hack_size"], _p(hell["hack_offsets"]), _p(hell["row_lengths"]), _p(ri),

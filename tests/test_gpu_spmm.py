@@ -149,3 +149,30 @@ def test_spmm_window_tile_with_ragged_rows(gpu, letter, hs, count, base):
         torch.cuda.synchronize()
         want = O.hell_spmm(hell, X, Y if beta != 0 else None, -1.5, beta)
         assert dZ.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_in_place_sum_leaves_rows_without_entries_untouched(gpu):
+    """Z += alpha*A*X (Z == Y, beta == 1): rows with rS == 0 are neither read nor written (spmm.h) -- even a -0.0
+    or a NaN sitting there survives -- and the other rows equal the oracle called the same way, bit for bit."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    rng = np.random.default_rng(12)
+    rows, count = 2000, 16
+    lengths = np.where(rng.random(rows) < 0.8, 0, rng.integers(1, 9, size=rows))
+    r = np.repeat(np.arange(rows), lengths)
+    c = rng.integers(0, rows, size=r.size)
+    v = synth.values_for("D", 7, r.size)
+    hell = formats.ell_to_hell(formats.coo_to_ell(rows, r, c, v), 32)
+    X = synth.values_for("D", 8, rows * count).reshape(rows, count)
+    Z0 = synth.values_for("D", 9, rows * count).reshape(rows, count)
+    empty = np.flatnonzero(lengths == 0)
+    Z0[empty[0::2]] = -0.0
+    Z0[empty[1::2]] = np.nan
+    mat = formats.DeviceHell(hell)
+    dX, dZ = formats.to_device(X), formats.to_device(Z0)
+    capi.hellspmm["D"](gpu, _p(dZ), _p(dZ), 0.5, _p(mat.cM), _p(mat.rP), mat.hack_size, _p(mat.hack_offsets), _p(mat.rS),
+                       None, 0, rows, _p(dX), 1.0, mat.base, count, count, count)
+    torch.cuda.synchronize()
+    got = dZ.cpu().numpy()
+    assert got[empty].tobytes() == Z0[empty].tobytes()
+    assert got.tobytes() == O.hell_spmm(hell, X, Z0, 0.5, 1.0, in_place=True).tobytes()
