@@ -1,6 +1,6 @@
 #pragma once
 /*
- * Device-side format construction: COO -> ELL and COO -> HELL entirely in HBM.
+ * Device-side format construction: COO -> ELL, COO -> HELL and COO -> HDIA entirely in HBM.
  * NEW: the reference converts on ONE host thread
  * (ell.c:39-80, hell.c:46-104) and uploads; for the 320 M nonzeros of BASELINE
  * configs[1] that is seconds of CPU time and a 3.8 GB PCIe copy per matrix.
@@ -58,6 +58,35 @@ spgpuStatus_t spgpuCooToHellDevice(spgpuHandle_t handle, __device void* hellValu
                                    const __device int* cooColsIndices, const __device void* cooValues,
                                    int cooBaseIndex, spgpuType_t valuesType, const __device int* rowLengths,
                                    __device void* work);
+
+/* ---- COO -> HDIA ---------------------------------------------------------------------------------------------
+ * Device counterparts of computeHdiaHackOffsetsFromCoo and cooToHdia (hdia.cpp:161-228, 230-349): same arrays,
+ * byte for byte, for the same COO input (any entry order; of several entries with one (row, column) the LAST in
+ * COO order is stored, as in the reference's in-order memcpy), hdiaValues zeroed by the caller.
+ * The plan sorts one 64-bit (hack, diagonal) key per entry (rocPRIM radix sort) and keeps the distinct ones. */
+
+/* Bytes of device scratch for spgpuCooHdiaPlanDevice (0 if no GPU can be asked for rocPRIM's share). */
+size_t spgpuCooHdiaPlanWorkBytes(int rowsCount, int nonZerosCount);
+
+/* Fills hackOffsets[hacks + 1] on the device (hacks = getHdiaHacksCount(hackSize, rowsCount)) and returns the number
+ * of stored diagonals in *allocationHeight (host); synchronises the stream.  Leaves the diagonal list in `work` for
+ * spgpuCooToHdiaDevice.  SPGPU_UNSUPPORTED if an entry lies outside the rowsCount x columnsCount matrix. */
+spgpuStatus_t spgpuCooHdiaPlanDevice(spgpuHandle_t handle, __host int* allocationHeight, __device int* hackOffsets,
+                                     int hackSize, int rowsCount, int columnsCount, int nonZerosCount,
+                                     const __device int* cooRowIndices, const __device int* cooColsIndices,
+                                     int cooBaseIndex, __device void* work);
+
+/* Bytes of the second scratch area of spgpuCooToHdiaDevice: one int per HDIA slot (hackSize * allocationHeight). */
+size_t spgpuCooToHdiaScratchBytes(int hackSize, int allocationHeight);
+
+/* Fills hdiaValues[hackSize * allocationHeight] (zeroed by the caller) and hdiaOffsets[allocationHeight].
+ * `work` as left by spgpuCooHdiaPlanDevice for the same COO arrays; `scratch` of spgpuCooToHdiaScratchBytes bytes. */
+spgpuStatus_t spgpuCooToHdiaDevice(spgpuHandle_t handle, __device void* hdiaValues, __device int* hdiaOffsets,
+                                   const __device int* hackOffsets, int hackSize, int rowsCount, int columnsCount,
+                                   int nonZerosCount, const __device int* cooRowIndices,
+                                   const __device int* cooColsIndices, const __device void* cooValues,
+                                   int cooBaseIndex, spgpuType_t valuesType, int allocationHeight,
+                                   const __device void* work, __device void* scratch);
 
 #ifdef __cplusplus
 }

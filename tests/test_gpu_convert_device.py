@@ -101,3 +101,101 @@ def test_degenerate_and_bad_input(gpu):
     rs = torch.empty(10, dtype=torch.int32, device="cuda:0")
     mx = C.c_int(0)
     assert capi.spgpuCooRowLengthsDevice(gpu, _p(rs), C.byref(mx), 10, 3, _p(r), 0, _p(work)) == capi.SPGPU_UNSUPPORTED
+
+
+# ---- COO -> HDIA ------------------------------------------------------------------------------------------------
+def _device_hdia(gpu, n_rows, n_cols, r, c, v, base, hack_size):
+    import torch
+    from spgpu_amd import capi, formats
+    letter = formats.LETTER_OF[np.dtype(v.dtype)]
+    nnz = int(r.size)
+    one = lambda a, dt: formats.to_device(a if a.size else np.zeros(1, dt))
+    dr, dc, dv = one(r.astype(np.int32), np.int32), one(c.astype(np.int32), np.int32), one(v, v.dtype)
+    work_bytes = capi.spgpuCooHdiaPlanWorkBytes(n_rows, nnz)
+    assert work_bytes > 0
+    work = torch.empty(work_bytes, dtype=torch.uint8, device="cuda:0")
+    hacks = capi.getHdiaHacksCount(hack_size, n_rows)
+    ho = torch.full((hacks + 1,), -1, dtype=torch.int32, device="cuda:0")
+    height = C.c_int(-1)
+    st = capi.spgpuCooHdiaPlanDevice(gpu, C.byref(height), _p(ho), hack_size, n_rows, n_cols, nnz, _p(dr), _p(dc), base, _p(work))
+    if st != capi.SPGPU_SUCCESS:
+        return st, None
+    slots = hack_size * height.value
+    values = torch.zeros(max(slots, 1), dtype=dv.dtype, device="cuda:0")
+    offsets = torch.zeros(max(height.value, 1), dtype=torch.int32, device="cuda:0")
+    scratch = torch.empty(capi.spgpuCooToHdiaScratchBytes(hack_size, height.value), dtype=torch.uint8, device="cuda:0")
+    st = capi.spgpuCooToHdiaDevice(gpu, _p(values), _p(offsets), _p(ho), hack_size, n_rows, n_cols, nnz, _p(dr), _p(dc), _p(dv),
+                                   base, capi.TYPE_CODE[letter], height.value, _p(work), _p(scratch))
+    torch.cuda.synchronize()
+    return st, dict(height=height.value, hack_offsets=ho.cpu().numpy(), values=values.cpu().numpy()[:slots],
+                    offsets=offsets.cpu().numpy()[:height.value])
+
+
+def _diagonal_coo(rng, letter, base, n_rows, n_cols, diagonals, fill, duplicates):
+    """Entries on a few diagonals (HDIA's home ground), each present with probability `fill`, some repeated with
+    other values, then shuffled."""
+    from spgpu_amd import synth
+    rows = np.arange(n_rows)
+    parts_r, parts_c = [], []
+    for d in diagonals:
+        keep = (rows + d >= 0) & (rows + d < n_cols) & (rng.random(n_rows) < fill)
+        parts_r.append(rows[keep])
+        parts_c.append(rows[keep] + d)
+    r, c = np.concatenate(parts_r), np.concatenate(parts_c)
+    if duplicates and r.size:
+        again = rng.integers(0, r.size, size=duplicates)
+        r, c = np.concatenate([r, r[again]]), np.concatenate([c, c[again]])
+    order = rng.permutation(r.size)
+    r, c = r[order], c[order]
+    v = synth.values_for(letter, int(rng.integers(1, 1 << 30)), r.size)
+    return (r + base).astype(np.int32), (c + base).astype(np.int32), v
+
+
+@pytest.mark.parametrize("letter", "SDCZ")
+def test_device_coo_to_hdia_matches_host(gpu, letter):
+    """Same hackOffsets, offsets and values as computeHdiaHackOffsetsFromCoo + cooToHdia, byte for byte: shuffled COO,
+    duplicates (the last one in COO order wins), both index bases, partly filled diagonals, rectangular matrices,
+    hack sizes 32/64/96, a last hack that is partly filled."""
+    from spgpu_amd import capi, formats
+    rng = np.random.default_rng(300 + ord(letter))
+    for trial in range(10):
+        base, hs = int(rng.integers(0, 2)), int(rng.choice([32, 64, 96]))
+        n_rows = int(rng.integers(1, 3000))
+        n_cols = n_rows if trial % 2 else int(rng.integers(1, 3000))
+        diagonals = np.unique(rng.integers(-n_rows + 1, n_cols, size=int(rng.integers(1, 12))))
+        r, c, v = _diagonal_coo(rng, letter, base, n_rows, n_cols, diagonals, float(rng.choice([1.0, 0.6, 0.05])),
+                                int(rng.integers(0, 50)))
+        host = formats.coo_to_hdia(n_rows, n_cols, r, c, v, hs, coo_base=base)
+        st, dev = _device_hdia(gpu, n_rows, n_cols, r, c, v, base, hs)
+        assert st == capi.SPGPU_SUCCESS
+        _same(dev, host, ("height", "hack_offsets", "offsets", "values"))
+
+
+def test_device_coo_to_hdia_scattered_and_empty(gpu):
+    """Not a diagonal matrix at all (every entry its own diagonal in its hack), an empty matrix, and an entry outside
+    the matrix (reported, as the ELL/HELL calls do)."""
+    from spgpu_amd import capi, formats
+    from test_oracle_vs_reference import _random_coo
+    rng = np.random.default_rng(41)
+    for _ in range(4):
+        n_rows, n_cols, r, c, v = _random_coo(rng, "D", 1)
+        host = formats.coo_to_hdia(n_rows, n_cols, r, c, v, 32, coo_base=1)
+        st, dev = _device_hdia(gpu, n_rows, n_cols, r, c, v, 1, 32)
+        assert st == capi.SPGPU_SUCCESS
+        _same(dev, host, ("height", "hack_offsets", "offsets", "values"))
+    none = np.zeros(0, dtype=np.int32)
+    st, dev = _device_hdia(gpu, 100, 100, none, none, np.zeros(0), 0, 32)
+    assert st == capi.SPGPU_SUCCESS and dev["height"] == 0 and not dev["hack_offsets"].any()
+    st, _ = _device_hdia(gpu, 10, 10, np.array([3, 10], dtype=np.int32), np.array([1, 1], dtype=np.int32), np.ones(2), 0, 32)
+    assert st == capi.SPGPU_UNSUPPORTED
+
+
+def test_device_hdia_laplacian(gpu):
+    """7-point Laplacian 48^3 (BASELINE configs[3]'s matrix family) from COO on the device: equals the host-built HDIA."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n, _, r, c, v = synth.laplacian_3d_7pt(48)
+    host = formats.coo_to_hdia(n, n, r, c, v, 32)
+    st, dev = _device_hdia(gpu, n, n, r, c, v, 0, 32)
+    assert st == capi.SPGPU_SUCCESS
+    _same(dev, host, ("height", "hack_offsets", "offsets", "values"))
