@@ -1,0 +1,31 @@
+#pragma once
+/*
+ * Tuning knobs of the gfx950 kernels (no counterpart in the reference, whose
+ * only compile-time knobs are THREAD_BLOCK / MAX_NNZ_PER_WG in the *_base.cuh
+ * files).  The library reads these environment variables ONCE, on the first
+ * call that needs them -- never in a launch path -- and again whenever
+ * spgpuTuningReload() is called (the A/B tools and the kernel-shape parity
+ * tests change them between launches):
+ *
+ *   SPGPU_SPMV_VARIANT   ELL/HELL SpMV kernel shape (0 = default, see csrc/ellpack_spmv.hip)
+ *   SPGPU_NT_LOADS       0: no non-temporal hint on the coefficient/index streams (default 1)
+ *   SPGPU_TAIL_LANES     busy lanes below which a wavefront switches to whole-wave rows (default 16)
+ *   SPGPU_HDIA_VARIANT   1: 4 diagonals per stage instead of 8
+ *   SPGPU_HDIA_BLOCK     HDIA workgroup size 256 (default) / 512 / 1024
+ *   SPGPU_HDIA_NARROW    1: one row per lane even when 16-byte accesses are possible
+ *   SPGPU_XCD_ORDER      HDIA: 0 hardware workgroup order (default), n: XCD-contiguous runs of n
+ *   SPGPU_SPMM_VARIANT   SpMM kernel shape (0 = default, see csrc/hell_spmm.hip)
+ *   SPGPU_L1_BLOCKS      grid cap of the Level-1 kernels (default 16384)
+ *
+ * Every setting computes the same values up to the summation order documented
+ * per kernel; the defaults are the measured best on MI355X.
+ */
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void spgpuTuningReload(void);
+
+#ifdef __cplusplus
+}
+#endif

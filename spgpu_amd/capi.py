@@ -179,6 +179,10 @@ spgpuCooToHdiaScratchBytes = _decl("spgpuCooToHdiaScratchBytes", C.c_size_t, [i3
 spgpuCooToHdiaDevice = _decl("spgpuCooToHdiaDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, i32, ptr, ptr])
 
 
+# ---- tuning.h: environment knobs are cached by the library; call after changing one ---------------------------
+spgpuTuningReload = _decl("spgpuTuningReload", None, [])
+
+
 def create_handle(device=0):
     h = Handle()
     status = spgpuCreate(C.byref(h), device)

@@ -6,6 +6,7 @@
  * kernels/ddot.cu:35).
  */
 #include "spgpu_internal.h"
+#include "spgpu/tuning.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -115,4 +116,37 @@ size_t spgpuSizeOf(spgpuType_t typeCode)
     case SPGPU_TYPE_COMPLEX_DOUBLE: return sizeof(hipDoubleComplex);
     default:                        return 0;
     }
+}
+
+/* ---- tuning knobs (include/spgpu/tuning.h) ---- */
+static SpgpuTuning tuning;
+static int tuningLoaded;
+
+static int envInt(const char* name, int fallback)
+{
+    const char* s = getenv(name);
+    return s && *s ? atoi(s) : fallback;
+}
+
+void spgpuTuningReload(void)
+{
+    SpgpuTuning t;
+    t.spmvVariant = envInt("SPGPU_SPMV_VARIANT", 0);
+    t.ntLoads = envInt("SPGPU_NT_LOADS", 1);
+    t.tailLanes = envInt("SPGPU_TAIL_LANES", -1);
+    t.hdiaVariant = envInt("SPGPU_HDIA_VARIANT", 0);
+    t.hdiaBlock = envInt("SPGPU_HDIA_BLOCK", 256);
+    t.hdiaNarrow = envInt("SPGPU_HDIA_NARROW", 0);
+    t.xcdOrder = envInt("SPGPU_XCD_ORDER", 0);
+    t.spmmVariant = envInt("SPGPU_SPMM_VARIANT", 0);
+    t.l1Blocks = envInt("SPGPU_L1_BLOCKS", 0);
+    tuning = t;
+    __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);
+}
+
+const SpgpuTuning* spgpuTuning(void)
+{
+    if (!__atomic_load_n(&tuningLoaded, __ATOMIC_ACQUIRE))
+        spgpuTuningReload(); /* two threads racing here store the same values */
+    return &tuning;
 }

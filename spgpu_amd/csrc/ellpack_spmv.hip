@@ -326,12 +326,6 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
 
 /* ---- host side ----------------------------------------------------------- */
 
-static int envInt(const char* name, int fallback)
-{
-    const char* s = getenv(name);
-    return s && *s ? atoi(s) : fallback;
-}
-
 static bool alignedTo(const void* p, size_t bytes)
 {
     return ((uintptr_t)p % bytes) == 0;
@@ -380,9 +374,10 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
      *   21 = 17 and 22 = 18 with the prefetch issued after the gathers (defaults for D/C and S)
      *   (5,7..11,14..16 exist only in -DSPGPU_TUNING_VARIANTS builds)
      * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams (default 1). */
-    a.tailLanes = envInt("SPGPU_TAIL_LANES", kTailLanes);
-    int variant = envInt("SPGPU_SPMV_VARIANT", 0);
-    const bool nt = envInt("SPGPU_NT_LOADS", 1) != 0;
+    const SpgpuTuning* tune = spgpuTuning();
+    a.tailLanes = tune->tailLanes >= 0 ? tune->tailLanes : kTailLanes;
+    int variant = tune->spmvVariant;
+    const bool nt = tune->ntLoads != 0;
     if (variant < 1 || variant > 24)
         variant = !wideOk ? 13 : (sizeof(T) == 4 ? 22 : 21);
     const bool narrowVariant = variant == 3 || variant == 4 || (variant >= 13 && variant <= 16);

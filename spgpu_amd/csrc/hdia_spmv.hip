@@ -169,8 +169,7 @@ template <typename T, int RPL, int UNROLL>
 static void launchHdia(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
 {
     /* SPGPU_HDIA_BLOCK (experiments): workgroup size 256 (default) / 512 / 1024 */
-    const char* bs = getenv("SPGPU_HDIA_BLOCK");
-    const int block = bs && *bs ? atoi(bs) : 256;
+    const int block = spgpuTuning()->hdiaBlock;
     if (block == 1024)
         launchHdiaSized<T, RPL, UNROLL, 1024>(stream, a, nt);
     else if (block == 512)
@@ -201,13 +200,11 @@ static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     a.hackSize = hackSize;
     a.flatDiags = flatDiags;
 
-    const char* xo = getenv("SPGPU_XCD_ORDER");
-    a.xcdOrder = xo && *xo ? atoi(xo) : 0;
+    const SpgpuTuning* tune = spgpuTuning();
+    a.xcdOrder = tune->xcdOrder;
     constexpr int WIDE = 16 / (int)sizeof(T);
-    const char* env = getenv("SPGPU_NT_LOADS");
-    const bool nt = !(env && *env == '0');
-    const char* force = getenv("SPGPU_HDIA_NARROW");
-    const bool wideOk = WIDE > 1 && hackSize % WIDE == 0 && ((uintptr_t)dM % 16 == 0) && !(force && *force == '1');
+    const bool nt = tune->ntLoads != 0;
+    const bool wideOk = WIDE > 1 && hackSize % WIDE == 0 && ((uintptr_t)dM % 16 == 0) && !tune->hdiaNarrow;
 
     hipStream_t stream = handle->currentStream;
     if constexpr (WIDE > 1) {
@@ -216,8 +213,7 @@ static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
             /* SPGPU_HDIA_VARIANT (experiments): 1 = 4 diagonals/stage, otherwise 8 (default).  Measured on 512^3
              * (tools/ab_hdia.py, profiles/): within 1 % of each other; XCD-contiguous block orders and
              * workgroups of 512/1024 lanes are 2-13 % slower than the hardware order with 256 lanes. */
-            const char* hv = getenv("SPGPU_HDIA_VARIANT");
-            if (hv && *hv == '1')
+            if (tune->hdiaVariant == 1)
                 launchHdia<T, WIDE, 4>(stream, a, nt);
             else
                 launchHdia<T, WIDE, 8>(stream, a, nt);

@@ -797,8 +797,7 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
         const bool pairs = pairsOk && a.count % 2 == 0;
         /* 16-byte loads of whole 32-row half columns */
         const bool strips = pairs && hackSize % 32 == 0 && (uintptr_t)cM % 16 == 0 && (uintptr_t)rP % 16 == 0;
-        const char* ev = getenv("SPGPU_SPMM_VARIANT"); /* experiments */
-        const int variant = ev && *ev ? atoi(ev) : 0;
+        const int variant = spgpuTuning()->spmmVariant; /* experiments, include/spgpu/tuning.h */
         if (a.count > 8) {
             if (pairs && variant == 1)
                 launchSpmm<T, 8, 2, 2>(stream, a);          /* plain: X rows through L1 */

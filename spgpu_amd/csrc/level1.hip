@@ -35,14 +35,8 @@ constexpr int kL1Threads = 256;
 constexpr int kL1MaxBlocksDefault = 16384; /* measured: 2 048 -> 64.7 %, 16 384 -> 71 % of 8 TB/s for axpby (tile-stride loop beyond) */
 static int l1MaxBlocks()
 {
-    static int cached = 0;
-    if (!cached) {
-        const char* e = getenv("SPGPU_L1_BLOCKS"); /* experiments */
-        cached = e && *e ? atoi(e) : kL1MaxBlocksDefault;
-        if (cached < 1)
-            cached = kL1MaxBlocksDefault;
-    }
-    return cached;
+    const int asked = spgpuTuning()->l1Blocks; /* experiments, include/spgpu/tuning.h */
+    return asked >= 1 ? asked : kL1MaxBlocksDefault;
 }
 
 /* ---- axpby ---------------------------------------------------------------

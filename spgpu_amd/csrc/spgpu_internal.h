@@ -33,6 +33,20 @@ static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
  * caller's own hipGetLastError(), again as in the reference. */
 void spgpuDebugCheck(spgpuHandle_t h, const char* what);
 
+/* Environment knobs (include/spgpu/tuning.h), read once and cached: no getenv in a launch path. */
+typedef struct SpgpuTuning {
+    int spmvVariant; /* 0 */
+    int ntLoads;     /* 1 */
+    int tailLanes;   /* -1: kernel default */
+    int hdiaVariant; /* 0 */
+    int hdiaBlock;   /* 256 */
+    int hdiaNarrow;  /* 0 */
+    int xcdOrder;    /* 0 */
+    int spmmVariant; /* 0 */
+    int l1Blocks;    /* 0: kernel default */
+} SpgpuTuning;
+const SpgpuTuning* spgpuTuning(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,3 +42,19 @@ def gpu():
     yield handle
     torch.cuda.synchronize()
     capi.spgpuDestroy(handle)
+
+
+@pytest.fixture
+def tuning(monkeypatch):
+    """Set tuning knobs of the library (include/spgpu/tuning.h) for one test: tuning(SPGPU_SPMV_VARIANT=3).
+    The library caches them, so they are reloaded here and again after the environment is restored."""
+    from spgpu_amd import capi
+
+    def set_knobs(**knobs):
+        for name, value in knobs.items():
+            monkeypatch.setenv(name, str(value))
+        capi.spgpuTuningReload()
+
+    yield set_knobs
+    monkeypatch.undo()
+    capi.spgpuTuningReload()

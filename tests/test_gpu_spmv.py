@@ -94,9 +94,9 @@ def test_fixture_parity_all_formats(gpu, name):
 
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 12, 13, 17, 18, 21, 22])
 @pytest.mark.parametrize("name", ["powerlaw_s_b1_h64", "powerlaw_d_b0_h32", "powerlaw_c_b0_h32", "powerlaw_z_b1_h64"])
-def test_every_kernel_variant_bit_exact(gpu, name, variant, monkeypatch):
+def test_every_kernel_variant_bit_exact(gpu, name, variant, tuning):
     from spgpu_amd import formats
-    monkeypatch.setenv("SPGPU_SPMV_VARIANT", str(variant))
+    tuning(SPGPU_SPMV_VARIANT=variant)
     g = _load(name)
     letter, ell, hell, _ = _mats(g)
     # Z (16-byte elements) has no wide form: wide requests run narrow 2x4 pipe

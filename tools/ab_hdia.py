@@ -26,6 +26,7 @@ for rnd in range(5):
     for s in settings:
         (os.environ["SPGPU_XCD_ORDER"], os.environ["SPGPU_NT_LOADS"], os.environ["SPGPU_HDIA_VARIANT"],
          os.environ["SPGPU_HDIA_BLOCK"]) = map(str, s)
+        capi.spgpuTuningReload()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
             call()

@@ -26,6 +26,7 @@ for pattern in sys.argv[1:] or ["banded", "random"]:
     for rnd in range(4):
         for v in variants:
             os.environ["SPGPU_SPMM_VARIANT"] = str(v)
+            capi.spgpuTuningReload()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(stream):
                 call()

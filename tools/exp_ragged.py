@@ -30,6 +30,7 @@ def run(h, label):
         variant, _, tl = variant.partition(":")
         os.environ["SPGPU_SPMV_VARIANT"] = variant
         os.environ["SPGPU_TAIL_LANES"] = tl or "8"
+        capi.spgpuTuningReload()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
             call(); call()

@@ -34,6 +34,7 @@ for pattern in patterns:
     for rnd in range(int(os.environ.get("SWEEP_ROUNDS", 3))):
         for v, nt in configs:
             os.environ["SPGPU_SPMV_VARIANT"], os.environ["SPGPU_NT_LOADS"] = str(v), str(nt)
+            capi.spgpuTuningReload()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(stream):
                 call(); call()
