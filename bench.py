@@ -253,6 +253,14 @@ def run_spmv(args, rank, world):
                                        frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4),
                                        parity=spot_check_hell(h, x, y, z, 1.0, 0.0))
             out["variants"] = extras
+            if world == 1:
+                # the N = 1 point of the curve `--gpus N` (N > 1) measures: same sharded SpMM step on one rank
+                del h, step, s2
+                torch.cuda.empty_cache()
+                one = measure_spmm(args, 0, 1, handle, stream, dev, 50, 5)
+                out["spmm_1gpu"] = dict(value=one["value"], unit=one["unit"], ms_per_step=one["ms_per_step"],
+                                        workload=one["config"]["workload"], roofline_frac=one["roofline"]["frac"],
+                                        kernel_ms=one["roofline"]["kernel_ms"], parity=one["parity"])
         elif "cpu_baseline" not in out:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
@@ -263,8 +271,7 @@ def run_spmm(args, rank, world):
     """Row-sharded HELL fp64 SpMM (BASELINE configs[4]): weak scaling, 5 M rows x 32 nnz per GPU, 16 rhs;
     one step = all-gather of the X row blocks over RCCL + the local product(s)."""
     import torch
-    import torch.distributed as dist
-    from spgpu_amd import capi, sharded, synth
+    from spgpu_amd import capi
 
     local = int(os.environ.get("LOCAL_RANK", 0))
     dev = f"cuda:{local}"
@@ -272,6 +279,18 @@ def run_spmm(args, rank, world):
     handle = capi.create_handle(torch.cuda.current_device())
     stream = torch.cuda.Stream()
     capi.spgpuSetStream(handle, C.c_void_p(stream.cuda_stream))
+    out = measure_spmm(args, rank, world, handle, stream, dev, args.steps, args.warmup)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    capi.spgpuDestroy(handle)
+
+
+def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
+    """The sharded SpMM step on `world` ranks (world == 1: the single-GPU point of the same curve).  Returns the
+    JSON record on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    from spgpu_amd import capi, sharded, synth
 
     rows_local, k, L = args.spmm_rows_per_gpu // 32 * 32, args.rhs, args.nnz_per_row
     n_total = rows_local * world
@@ -303,7 +322,7 @@ def run_spmm(args, rank, world):
         op.step(z_local, y_local, 1.0, x_local, 0.0)
 
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
     torch.cuda.synchronize()
     if world > 1:
@@ -311,7 +330,7 @@ def run_spmm(args, rank, world):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
-        for _ in range(args.steps):
+        for _ in range(steps):
             step()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -371,8 +390,8 @@ def run_spmm(args, rank, world):
             parity = "bit-exact vs oracle on 1024 rows" if got.tobytes() == want.tobytes() else "MISMATCH"
         out = dict(
             metric="HELL fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), 1 GPU",
-            value=round(flops_total * args.steps / wall * 1e-9, 2), unit="GFLOP/s", n_gpus=world, steps=args.steps,
-            warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 5), higher_is_better=True, scaling="weak",
+            value=round(flops_total * steps / wall * 1e-9, 2), unit="GFLOP/s", n_gpus=world, steps=steps,
+            warmup=warmup, ms_per_step=round(wall / steps * 1e3, 5), higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f64", data="synthetic",
             config=dict(workload=f"row-sharded HELL fp64 SpMM (spgpuDhellspmm), {rows_local} rows/GPU x {L} nnz/row x {k} rhs, "
                                  f"{n_total} rows total, columns {args.spmm_pattern}, RCCL all-gather(X) per step "
@@ -386,8 +405,8 @@ def run_spmm(args, rank, world):
                       compute_only_gflops_total=round(flops_total / t_compute * 1e-9, 1),
                       allgather_GBps_per_rank=round((world - 1) * rows_local * k * 8 / t_gather * 1e-9, 1) if t_gather else None),
             parity=parity, cpu_baseline=None)
-        print(json.dumps(out), flush=True)
-    capi.spgpuDestroy(handle)
+        return out
+    return None
 
 
 def main():
