@@ -179,6 +179,15 @@ spgpuCooToHdiaScratchBytes = _decl("spgpuCooToHdiaScratchBytes", C.c_size_t, [i3
 spgpuCooToHdiaDevice = _decl("spgpuCooToHdiaDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, i32, ptr, ptr])
 
 
+# ---- device_scalars.h (new: results and coefficients in device memory, graph-capturable) ---------------------
+dot_device, axpby_device, axpby_quot_device, div_device = {}, {}, {}, {}
+for _L in "SD":
+    dot_device[_L] = _decl(f"spgpu{_L}dotDevice", None, [Handle, ptr, i32, ptr, ptr])
+    axpby_device[_L] = _decl(f"spgpu{_L}axpbyDevice", None, [Handle, ptr, i32, ptr, ptr, ptr, ptr])
+    axpby_quot_device[_L] = _decl(f"spgpu{_L}axpbyQuotDevice", None, [Handle, ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, ptr])
+    div_device[_L] = _decl(f"spgpu{_L}divDevice", None, [Handle, ptr, ptr, ptr, i32])
+
+
 # ---- tuning.h: environment knobs are cached by the library; call after changing one ---------------------------
 spgpuTuningReload = _decl("spgpuTuningReload", None, [])
 

@@ -24,6 +24,7 @@
 #include "spgpu_internal.h"
 
 #include "spgpu/vector.h"
+#include "spgpu/device_scalars.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -51,8 +52,7 @@ __device__ inline cdouble axpbyOne(cdouble alpha, cdouble x, cdouble beta, cdoub
 constexpr int kL1Unroll = 4; /* independent 16-byte accesses in flight per lane */
 
 template <typename T, int VEC, bool HAS_BETA>
-__global__ __launch_bounds__(kL1Threads) void axpbyKernel(T* z, int n, T beta, const T* y, T alpha, const T* x,
-                                                         long long pitch)
+__device__ inline void axpbyBody(T* z, int n, T beta, const T* y, T alpha, const T* x, long long pitch)
 {
     const long long shift = (long long)blockIdx.y * pitch;
     z += shift;
@@ -97,6 +97,46 @@ __global__ __launch_bounds__(kL1Threads) void axpbyKernel(T* z, int n, T beta, c
         else
             z[tail] = mul(alpha, x[tail]);
     }
+}
+
+template <typename T, int VEC, bool HAS_BETA>
+__global__ __launch_bounds__(kL1Threads) void axpbyKernel(T* z, int n, T beta, const T* y, T alpha, const T* x,
+                                                         long long pitch)
+{
+    axpbyBody<T, VEC, HAS_BETA>(z, n, beta, y, alpha, x, pitch);
+}
+
+/* scalars from device memory (include/spgpu/device_scalars.h): the same two bodies, chosen by the value of beta.
+ * A coefficient is num/den (NULL = 1); hasBeta == 0: no y at all. */
+template <typename T> __device__ inline T quotientAt(const T* num, const T* den)
+{
+    if (num && den)
+        return *num / *den;
+    if (num)
+        return *num;
+    return den ? T(1) / *den : T(1);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(kL1Threads) void axpbyDeviceKernel(T* z, int n, int hasBeta, const T* betaNum, const T* betaDen,
+                                                               const T* y, const T* alphaNum, const T* alphaDen,
+                                                               int negateAlpha, const T* x)
+{
+    T alpha = quotientAt(alphaNum, alphaDen);
+    if (negateAlpha)
+        alpha = -alpha;
+    const T beta = hasBeta ? quotientAt(betaNum, betaDen) : zeroOf<T>();
+    if (isNotZero(beta))
+        axpbyBody<T, VEC, true>(z, n, beta, y, alpha, x, 0);
+    else
+        axpbyBody<T, VEC, false>(z, n, beta, y, alpha, x, 0);
+}
+
+template <typename T>
+__global__ void divDeviceKernel(T* out, const T* num, const T* den, int negate)
+{
+    const T q = *num / *den;
+    *out = negate ? -q : q;
 }
 
 template <typename T, typename ApiT>
@@ -255,6 +295,7 @@ __global__ __launch_bounds__(kL1Threads) void reduceKernel(typename AccOf<T, MOD
     const Acc total = blockCombine<MODE>(acc, lds);
     if (threadIdx.x == 0)
         partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = total;
+
 }
 
 /* Runs the two-stage reduction for `count` vectors and leaves one host value
@@ -307,6 +348,87 @@ static void reduceVectors(spgpuHandle_t handle, typename AccOf<T, MODE>::type* o
         }
     }
     spgpuDebugCheck(handle, "reduction");
+}
+
+/* Second stage on the device (device_scalars.h): the block partials are added in block order -- the order, and so the
+ * bits, of reduceVectors' host loop.  That is ONE dependent chain of additions; the workgroup first copies the
+ * partials to LDS (parallel loads), then lane 0 runs the chain with the operands of the next 16 steps already on
+ * their way from LDS.  (Finalising inside reduceKernel by the workgroup that arrives last was measured slower:
+ * every workgroup then pays a device-scope fence, 16.6 us against 5.0 + 3 us per dot of 2^20 doubles.) */
+template <typename Acc, int MODE>
+__global__ __launch_bounds__(kL1Threads) void reduceFinalKernel(Acc* result, const Acc* partials, int blocks)
+{
+    constexpr int STEP = 16;
+    __shared__ Acc all[SPGPU_REDUCE_MAX_BLOCKS + 2 * STEP];
+    for (int k = threadIdx.x; k < SPGPU_REDUCE_MAX_BLOCKS + 2 * STEP; k += kL1Threads)
+        all[k] = k < blocks ? partials[k] : zeroOf<Acc>(); /* + 0 changes nothing: the chain starts at +0 */
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    Acc sum = zeroOf<Acc>(), now[STEP], next[STEP];
+#pragma unroll
+    for (int u = 0; u < STEP; ++u)
+        now[u] = all[u];
+    for (int k0 = 0; k0 < blocks; k0 += STEP) {
+#pragma unroll
+        for (int u = 0; u < STEP; ++u)
+            next[u] = all[k0 + STEP + u];
+#pragma unroll
+        for (int u = 0; u < STEP; ++u)
+            sum = combine<MODE>(sum, now[u]);
+#pragma unroll
+        for (int u = 0; u < STEP; ++u)
+            now[u] = next[u];
+    }
+    *result = sum;
+}
+
+/* dot with the result left in device memory: same first stage and same grid as reduceVectors for one vector;
+ * no copy, no synchronisation (capturable in a graph). */
+template <typename T>
+static void dotToDevice(spgpuHandle_t handle, T* result, int n, const T* a, const T* b)
+{
+    hipStream_t s = handle->currentStream;
+    T* dev = static_cast<T*>(spgpuPrivate(handle)->reduceScratch);
+    long long blocks = 0;
+    if (n > 0) {
+        constexpr int WIDE = 16 / (int)sizeof(T);
+        const bool wide = WIDE > 1 && ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
+        const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
+        blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
+        if (blocks > SPGPU_REDUCE_MAX_BLOCKS)
+            blocks = SPGPU_REDUCE_MAX_BLOCKS;
+        const dim3 grid((unsigned)blocks, 1);
+        if (wide)
+            hipLaunchKernelGGL((reduceKernel<T, WIDE, kDot>), grid, dim3(kL1Threads), 0, s, dev, n, a, b, 0ll);
+        else
+            hipLaunchKernelGGL((reduceKernel<T, 1, kDot>), grid, dim3(kL1Threads), 0, s, dev, n, a, b, 0ll);
+    }
+    hipLaunchKernelGGL((reduceFinalKernel<T, kDot>), dim3(1), dim3(kL1Threads), 0, s, result, dev, (int)blocks);
+    spgpuDebugCheck(handle, "dotDevice");
+}
+
+template <typename T>
+static void axpbyFromDevice(spgpuHandle_t handle, T* z, int n, int hasBeta, const T* betaNum, const T* betaDen, const T* y,
+                            const T* alphaNum, const T* alphaDen, int negateAlpha, const T* x)
+{
+    if (n <= 0)
+        return;
+    constexpr int WIDE = 16 / (int)sizeof(T);
+    /* y may be ignored at run time (beta == 0); its alignment is required only when it is given */
+    const bool wide = ((uintptr_t)z % 16 == 0) && ((uintptr_t)x % 16 == 0) && (!hasBeta || !y || (uintptr_t)y % 16 == 0);
+    const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
+    long long blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
+    if (blocks > l1MaxBlocks())
+        blocks = l1MaxBlocks();
+    hipStream_t s = handle->currentStream;
+    if (wide)
+        hipLaunchKernelGGL((axpbyDeviceKernel<T, WIDE>), dim3((unsigned)blocks), dim3(kL1Threads), 0, s, z, n, hasBeta, betaNum,
+                           betaDen, y, alphaNum, alphaDen, negateAlpha, x);
+    else
+        hipLaunchKernelGGL((axpbyDeviceKernel<T, 1>), dim3((unsigned)blocks), dim3(kL1Threads), 0, s, z, n, hasBeta, betaNum,
+                           betaDen, y, alphaNum, alphaDen, negateAlpha, x);
+    spgpuDebugCheck(handle, "axpbyDevice");
 }
 
 /* ---- element-wise maps: scal, abs, axy, axypbz -------------------------------
@@ -629,4 +751,22 @@ void spgpuIscat(spgpuHandle_t h, int* y, int xNnz, const int* xValues, const int
 void spgpuIsetscal(spgpuHandle_t h, int first, int last, int baseIndex, int val, int* y)
 { setscal<int>(h, first, last, baseIndex, val, y); }
 
+
+/* ---- include/spgpu/device_scalars.h ---- */
+void spgpuSdotDevice(spgpuHandle_t h, float* result, int n, const float* a, const float* b) { dotToDevice<float>(h, result, n, a, b); }
+void spgpuDdotDevice(spgpuHandle_t h, double* result, int n, const double* a, const double* b) { dotToDevice<double>(h, result, n, a, b); }
+void spgpuSaxpbyDevice(spgpuHandle_t h, float* z, int n, const float* beta, const float* y, const float* alpha, const float* x)
+{ axpbyFromDevice<float>(h, z, n, beta != nullptr, beta, nullptr, y, alpha, nullptr, 0, x); }
+void spgpuSaxpbyQuotDevice(spgpuHandle_t h, float* z, int n, const float* betaNum, const float* betaDen, const float* y,
+                           const float* alphaNum, const float* alphaDen, int negateAlpha, const float* x)
+{ axpbyFromDevice<float>(h, z, n, 1, betaNum, betaDen, y, alphaNum, alphaDen, negateAlpha, x); }
+void spgpuDaxpbyDevice(spgpuHandle_t h, double* z, int n, const double* beta, const double* y, const double* alpha, const double* x)
+{ axpbyFromDevice<double>(h, z, n, beta != nullptr, beta, nullptr, y, alpha, nullptr, 0, x); }
+void spgpuDaxpbyQuotDevice(spgpuHandle_t h, double* z, int n, const double* betaNum, const double* betaDen, const double* y,
+                           const double* alphaNum, const double* alphaDen, int negateAlpha, const double* x)
+{ axpbyFromDevice<double>(h, z, n, 1, betaNum, betaDen, y, alphaNum, alphaDen, negateAlpha, x); }
+void spgpuSdivDevice(spgpuHandle_t h, float* out, const float* num, const float* den, int negate)
+{ hipLaunchKernelGGL(divDeviceKernel<float>, dim3(1), dim3(1), 0, h->currentStream, out, num, den, negate); }
+void spgpuDdivDevice(spgpuHandle_t h, double* out, const double* num, const double* den, int negate)
+{ hipLaunchKernelGGL(divDeviceKernel<double>, dim3(1), dim3(1), 0, h->currentStream, out, num, den, negate); }
 } // extern "C"
