@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--rhs", type=int, default=16)
     p.add_argument("--spmm-pattern", default="banded", choices=["banded", "random", "window"])
     p.add_argument("--force-split", action="store_true", help="spmm: cut by column ownership even on one rank (rehearsal)")
+    p.add_argument("--exchange", default="needed", choices=["needed", "allgather"],
+                   help="spmm on N>1 ranks: move only the X rows the off-block columns name (one all_to_all per step), or "
+                        "all-gather the whole of X; with 'needed' the all-gather step is timed as well and reported beside it")
     p.add_argument("--no-split", action="store_true",
                    help="spmm: do not cut the local block by column ownership (no compute/all-gather overlap)")
     return p.parse_args()
@@ -314,8 +317,16 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
         capi.hellspmm["D"](handle, p(Z), p(Y), C.c_double(alpha), p(part["cM"]), p(part["rP"]), 32, p(part["hack_offsets"]),
                            p(part["rS"]), None, L, part["rows"], p(X), C.c_double(beta), 0, k, k, k)
 
-    op = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product,
-                             lambda rows: torch.empty(rows, k, dtype=torch.float64, device=dev))
+    new_rows = lambda rows: torch.empty(rows, k, dtype=torch.float64, device=dev)
+    needed_mode = split and args.exchange == "needed"
+    if needed_mode:
+        # only the X rows A_rest names travel: its columns are renumbered into that sorted list
+        needed, compact = sharded.needed_rows_of(rest["rP"], 0)
+        rest_compact = dict(rest, rP=compact.contiguous())
+        op = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest_compact, local_product, new_rows, needed=needed)
+        op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows)
+    else:
+        op = op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows)
     torch.cuda.synchronize()
 
     def step():
@@ -356,15 +367,39 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
             local_product(own, z_local, y_local, 1.0, op.x_full, 0.0)
         else:
             local_product(own, z_local, y_local, 1.0, x_local, 0.0)
-            local_product(rest, z_local, z_local, 1.0, op.x_full, 1.0)
+            if needed_mode:
+                local_product(rest_compact, z_local, z_local, 1.0, op.needed.x_needed, 1.0)
+            else:
+                local_product(rest, z_local, z_local, 1.0, op.x_full, 1.0)
 
     def gather_only():
-        w = op.gather_x(x_local, async_op=False)
+        w = op_allgather.gather_x(x_local, async_op=False)
         if w is not None:
             w.wait()
 
+    def needed_only():
+        w = op.needed.start(x_local, async_op=False)
+        if w is not None:
+            w.wait()
+
+    distributed = world > 1 or (dist.is_available() and dist.is_initialized())
     t_compute = timed(products_only, 10)
-    t_gather = timed(gather_only, 10) if world > 1 else 0.0
+    t_gather = timed(gather_only, 10) if distributed else 0.0
+    t_needed = timed(needed_only, 10) if needed_mode and distributed else 0.0
+    # the all-gather step beside the needed-rows step (same products, whole X moved)
+    t_step_allgather = 0.0
+    if needed_mode and distributed:
+        t_step_allgather = timed(lambda: op_allgather.step(z_local, y_local, 1.0, x_local, 0.0), max(3, steps // 10))
+        if world > 1:
+            t = torch.tensor([t_step_allgather], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_step_allgather = float(t.item())
+    # X as a whole for the parity check below (every rank takes part in the collective), then the step under test last
+    gather_only()
+    with torch.cuda.stream(stream):
+        step()
+    torch.cuda.synchronize()
+    x_everywhere = op_allgather.x_full
     nnz_local = rows_local * L
     hacks = rows_local // 32
     alg = hell_algorithmic_bytes(nnz_local, rows_local, n_total, hacks, rhs=k)
@@ -375,13 +410,11 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import numpy as np
         import oracle_api as O
-        step()
-        torch.cuda.synchronize()
         whole = synth.hell_uniform_on_device(rows_local, L, args.spmm_pattern, "D", 32, seed=11 + rank, device=dev,
                                              n_cols=n_total, row_offset=first) if split else own
         torch.cuda.synchronize()
         sub = synth.hell_rows_to_host(whole, 0, 1024)
-        want = O.hell_spmm(sub, op.x_full.cpu().numpy(), None, 1.0, 0.0)
+        want = O.hell_spmm(sub, x_everywhere.cpu().numpy(), None, 1.0, 0.0)
         got = z_local[:1024].cpu().numpy()
         if split:
             ok = np.max(np.abs(got - want) / (np.abs(want) + 1.0)) <= 1e-12
@@ -394,16 +427,23 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
             warmup=warmup, ms_per_step=round(wall / steps * 1e3, 5), higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f64", data="synthetic",
             config=dict(workload=f"row-sharded HELL fp64 SpMM (spgpuDhellspmm), {rows_local} rows/GPU x {L} nnz/row x {k} rhs, "
-                                 f"{n_total} rows total, columns {args.spmm_pattern}, RCCL all-gather(X) per step "
-                                 f"(BASELINE configs[4] at 8 GPUs)",
+                                 f"{n_total} rows total, columns {args.spmm_pattern}, "
+                                 + ("needed X rows per step by RCCL all_to_all" if needed_mode else "RCCL all-gather(X) per step")
+                                 + " (BASELINE configs[4] at 8 GPUs)",
                         rows_per_gpu=rows_local, rows_total=n_total, rhs=k, pattern=args.spmm_pattern,
-                        parallelism=f"row partition x{world}, all-gather of X" + (", own/rest column split (overlap)" if split else "")),
+                        exchange="needed rows (all_to_all)" if needed_mode else "all-gather",
+                        parallelism=f"row partition x{world}, " + ("needed-rows exchange" if needed_mode else "all-gather of X")
+                                    + (", own/rest column split (overlap)" if split else "")),
             roofline=dict(bound="hbm", achieved=round(alg / t_compute * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                           frac=round(alg / t_compute * 1e-9 / HBM_PEAK_GBS, 4), traffic=None, kernel="hellSpmmStripKernel<double,2>",
                           algorithmic_bytes_per_launch=alg, kernel_ms=round(t_compute * 1e3, 4)),
             spmm=dict(compute_only_ms=round(t_compute * 1e3, 4), allgather_only_ms=round(t_gather * 1e3, 4),
                       compute_only_gflops_total=round(flops_total / t_compute * 1e-9, 1),
-                      allgather_GBps_per_rank=round((world - 1) * rows_local * k * 8 / t_gather * 1e-9, 1) if t_gather else None),
+                      allgather_GBps_per_rank=round((world - 1) * rows_local * k * 8 / t_gather * 1e-9, 1) if t_gather else None,
+                      needed_rows_only_ms=round(t_needed * 1e3, 4) if needed_mode else None,
+                      needed_rows_received_per_rank=(sum(op.needed.recv_splits) - op.needed.recv_splits[rank]) if needed_mode else None,
+                      allgather_step_ms=round(t_step_allgather * 1e3, 4) if t_step_allgather else None,
+                      allgather_step_gflops_total=round(flops_total / t_step_allgather * 1e-9, 1) if t_step_allgather else None),
             parity=parity, cpu_baseline=None)
         return out
     return None

@@ -12,6 +12,14 @@ flight on the communication stream, then A_rest * X_full is accumulated (beta = 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): an all-gather in which every rank sends its
 block to its 7 peers uses all links at once; per link it moves one block.
 
+Needed-rows exchange (`exchange="needed"`): A_rest only reads the X rows its column indices name.  At set-up
+every rank lists those rows (sorted, unique), tells each owner which of its rows it wants (one all_to_all of
+counts, one of indices) and renumbers A_rest's columns into that compact list; a step then moves exactly the
+needed rows with ONE all_to_all (RCCL send/recv pairs, so only links between ranks that share columns carry
+data) instead of the whole of X.  For a banded matrix that is a halo of a few rows per neighbour; for scattered
+columns it degenerates to the all-gather's volume.  Same arithmetic as the all-gather path: A_own*X_own first,
+then Z += A_rest*X_needed.
+
 Nothing here computes on the CPU: `local_product` is injected (the C ABI on GPUs, the oracle in
 the gloo test).
 """
@@ -60,6 +68,51 @@ def split_by_column_owner(coo_rows, coo_cols, coo_vals, col_first, col_count, ba
     return pick(own), pick(~own)
 
 
+def needed_rows_of(rest_indices, base=0):
+    """Sorted unique X rows (global, zero-based) the column indices of A_rest name -- a torch tensor on the device
+    of `rest_indices` -- and the indices renumbered into that list (padding slots of the HELL slab included: they
+    hold a valid index with a zero coefficient)."""
+    import torch
+    cols = rest_indices.to(torch.int64) - base
+    needed = torch.unique(cols)                      # sorted
+    return needed, torch.searchsorted(needed, cols).to(rest_indices.dtype)
+
+
+class NeededRows:
+    """The X rows of other ranks one rank needs, and the per-step all_to_all that fetches them."""
+
+    def __init__(self, dist, rank, world, col_blocks, needed, new_rows):
+        import torch
+        self.dist, self.rank, self.world = dist, rank, world
+        dev = needed.device
+        starts = torch.tensor([f for f, _ in col_blocks], dtype=torch.int64, device=dev)
+        owner = torch.bucketize(needed, starts[1:], right=True)            # block r holds starts[r] .. starts[r+1]-1
+        want = torch.bincount(owner, minlength=world).to(torch.int64)       # rows I want from each rank
+        give = torch.empty_like(want)
+        dist.all_to_all_single(give, want)                                  # rows each rank wants from me
+        self.recv_splits = [int(v) for v in want.tolist()]
+        self.send_splits = [int(v) for v in give.tolist()]
+        ask = needed - starts[owner]                                        # row numbers inside the owner's block
+        self.send_index = torch.empty(sum(self.send_splits), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(self.send_index, ask, output_split_sizes=self.send_splits,
+                               input_split_sizes=self.recv_splits)
+        self.x_needed = new_rows(int(needed.numel()))
+        self.send_buffer = None
+
+    def start(self, x_local, async_op=True):
+        """Gathers the rows the other ranks asked for and starts the exchange into x_needed."""
+        import torch
+        if self.send_buffer is None:
+            self.send_buffer = torch.empty((self.send_index.numel(),) + tuple(x_local.shape[1:]), dtype=x_local.dtype,
+                                           device=x_local.device)
+        torch.index_select(x_local, 0, self.send_index, out=self.send_buffer)
+        return self.dist.all_to_all_single(self.x_needed, self.send_buffer, output_split_sizes=self.recv_splits,
+                                           input_split_sizes=self.send_splits, async_op=async_op)
+
+    def bytes_received(self, row_bytes):
+        return (sum(self.recv_splits) - self.recv_splits[self.rank]) * row_bytes
+
+
 class ShardedSpmm:
     """One rank's state for the sharded product.
 
@@ -68,12 +121,16 @@ class ShardedSpmm:
     dict for the oracle) with interleaved X / Y / Z.
     """
 
-    def __init__(self, dist, rank, world, col_blocks, own, rest, local_product, new_full_x, comm_stream=None):
+    def __init__(self, dist, rank, world, col_blocks, own, rest, local_product, new_full_x, comm_stream=None,
+                 needed=None):
+        """needed: sorted unique X rows `rest` reads (needed_rows_of), with rest's columns already renumbered into
+        that list -> a step exchanges only those rows.  None: a step all-gathers X (rest indexes the whole of X)."""
         self.dist, self.rank, self.world = dist, rank, world
+        self.needed = NeededRows(dist, rank, world, col_blocks, needed, new_full_x) if needed is not None else None
         self.col_blocks = col_blocks                  # [(first, count)] ownership of X rows per rank
         self.own, self.rest = own, rest               # rest is None when the block is not split
         self.local_product = local_product
-        self.x_full = new_full_x(sum(c for _, c in col_blocks))
+        self.x_full = new_full_x(sum(c for _, c in col_blocks)) if needed is None else None
         self.comm_stream = comm_stream
         counts = {c for _, c in col_blocks}
         self.equal_blocks = len(counts) == 1
@@ -106,9 +163,12 @@ class ShardedSpmm:
                 work.wait()
             self.local_product(self.own, z_local, y_local, alpha, self.x_full, beta)
             return
-        work = self.gather_x(x_local, async_op=True)
+        if self.needed is not None:
+            work, x_rest = self.needed.start(x_local), self.needed.x_needed
+        else:
+            work, x_rest = self.gather_x(x_local, async_op=True), self.x_full
         # columns of `own` are indexed relative to this rank's X block
         self.local_product(self.own, z_local, y_local, alpha, x_local, beta)
         if work is not None:
             work.wait()
-        self.local_product(self.rest, z_local, z_local, alpha, self.x_full, 1.0)
+        self.local_product(self.rest, z_local, z_local, alpha, x_rest, 1.0)

@@ -25,7 +25,7 @@ def _build_problem():
     return n, r, c, v, X, Y
 
 
-def _worker(rank, world, port, split, out_dir):
+def _worker(rank, world, port, split, out_dir, exchange="allgather"):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -55,11 +55,21 @@ def _worker(rank, world, port, split, out_dir):
             res = O.hell_spmm(part, Xt.numpy(), None if beta == 0 else Yt.numpy(), alpha, beta)
             Z.copy_(torch.from_numpy(res))
 
+        needed = None
+        if exchange == "needed":
+            needed, renumbered = sharded.needed_rows_of(torch.from_numpy(rest["indices"]), rest["base"])
+            rest = dict(rest, indices=renumbered.numpy(), base=0)
         op = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product,
-                                 lambda rows: torch.zeros(rows, X.shape[1], dtype=torch.float64))
+                                 lambda rows: torch.zeros(rows, X.shape[1], dtype=torch.float64), needed=needed)
         z = torch.zeros(count, X.shape[1], dtype=torch.float64)
-        op.step(z, torch.from_numpy(Y[first:first + count].copy()), 1.5, torch.from_numpy(X[first:first + count].copy()), -0.5)
-        assert np.array_equal(op.x_full.numpy(), X), "all-gather did not reassemble X"
+        for _ in range(2):   # a second step reuses the exchange plan and its buffers
+            op.step(z, torch.from_numpy(Y[first:first + count].copy()), 1.5, torch.from_numpy(X[first:first + count].copy()), -0.5)
+        if exchange == "needed":
+            assert np.array_equal(op.needed.x_needed.numpy(), X[needed.numpy()]), "exchange did not deliver the rows asked for"
+            others = ~((needed.numpy() >= first) & (needed.numpy() < first + count))
+            assert op.needed.bytes_received(8 * X.shape[1]) == int(others.sum()) * 8 * X.shape[1]
+        else:
+            assert np.array_equal(op.x_full.numpy(), X), "all-gather did not reassemble X"
         np.save(os.path.join(out_dir, f"z{rank}.npy"), z.numpy())
         dist.barrier()
     finally:
@@ -81,6 +91,20 @@ def test_two_rank_sharded_spmm_matches_single_process(tmp_path, split):
         assert np.max(np.abs(got - want) / scale) <= 1e-12
     else:
         assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_needed_rows_exchange_matches_single_process(tmp_path, world):
+    """exchange="needed": only the X rows A_rest names travel (one all_to_all per step); three ranks so that the
+    request lists have different lengths per pair."""
+    import oracle_api as O
+    port = 29500 + (os.getpid() % 1000) + 20 + world
+    mp.spawn(_worker, args=(world, port, True, str(tmp_path), "needed"), nprocs=world, join=True)
+    n, r, c, v, X, Y = _build_problem()
+    hell = O.oracle_converters.ell_to_hell(O.oracle_converters.coo_to_ell(n, r, c, v), 32)
+    want = O.hell_spmm(hell, X, Y, 1.5, -0.5)
+    got = np.concatenate([np.load(tmp_path / f"z{k}.npy") for k in range(world)])
+    assert np.max(np.abs(got - want) / (np.abs(want) + 1.0)) <= 1e-12
 
 
 def test_partition_and_shard_are_consistent():
