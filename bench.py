@@ -164,10 +164,10 @@ def cpu_baseline(h, x, seconds):
 
 def run_spmv(args, rank, world):
     import torch
-    import torch.distributed as dist
     from spgpu_amd import capi, synth
 
-    dev = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+    dist = collectives()
+    dev = local_device()
     torch.cuda.set_device(dev)
     handle = capi.create_handle(torch.cuda.current_device())
     stream = torch.cuda.Stream()
@@ -276,8 +276,7 @@ def run_spmm(args, rank, world):
     import torch
     from spgpu_amd import capi
 
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    dev = f"cuda:{local}"
+    dev = local_device()
     torch.cuda.set_device(dev)
     handle = capi.create_handle(torch.cuda.current_device())
     stream = torch.cuda.Stream()
@@ -292,9 +291,9 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
     """The sharded SpMM step on `world` ranks (world == 1: the single-GPU point of the same curve).  Returns the
     JSON record on rank 0, None elsewhere."""
     import torch
-    import torch.distributed as dist
     from spgpu_amd import capi, sharded, synth
 
+    dist = collectives()
     rows_local, k, L = args.spmm_rows_per_gpu // 32 * 32, args.rhs, args.nnz_per_row
     n_total = rows_local * world
     first = rank * rows_local
@@ -449,6 +448,61 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
     return None
 
 
+def rehearsing():
+    return os.environ.get("SPGPU_BENCH_BACKEND") == "gloo"
+
+
+def local_device():
+    return "cuda:0" if rehearsing() else f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+
+
+def collectives():
+    import torch.distributed as dist
+    return HostStagedCollectives(dist) if rehearsing() else dist
+
+
+class HostStagedCollectives:
+    """Rehearsal only (SPGPU_BENCH_BACKEND=gloo): the collectives bench.py uses, staged through host memory over gloo,
+    so that several ranks can share the one GPU of a test box (RCCL refuses two ranks on one device).  Same call
+    signatures as torch.distributed; nothing here is timed for the record."""
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def is_available(self):
+        return True
+
+    def is_initialized(self):
+        return True
+
+    def barrier(self):
+        self._d.barrier()
+
+    def all_reduce(self, t, op=None):
+        import torch
+        torch.cuda.synchronize()
+        h = t.cpu()
+        self._d.all_reduce(h, op=op if op is not None else self._d.ReduceOp.SUM)
+        t.copy_(h)
+
+    def all_gather_into_tensor(self, out, inp, async_op=False):
+        import torch
+        torch.cuda.synchronize()
+        parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(self._d.get_world_size())]
+        self._d.all_gather(parts, inp.cpu())
+        out.copy_(torch.cat(parts, 0).view(out.shape))
+        return None
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, async_op=False):
+        import torch
+        torch.cuda.synchronize()
+        h = torch.empty(out.shape, dtype=out.dtype)
+        self._d.all_to_all_single(h, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+        out.copy_(h)
+        return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -463,8 +517,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(local_device())
+        dist.init_process_group("gloo" if rehearsing() else "nccl")
     workload = args.workload if args.workload != "auto" else ("spmv" if world == 1 else "spmm")
     try:
         (run_spmv if workload == "spmv" else run_spmm)(args, rank, world)
