@@ -179,6 +179,13 @@ spgpuCooToHdiaScratchBytes = _decl("spgpuCooToHdiaScratchBytes", C.c_size_t, [i3
 spgpuCooToHdiaDevice = _decl("spgpuCooToHdiaDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, i32, ptr, ptr])
 
 
+# ---- mmread.h (C wrappers of the Matrix Market reader) --------------------------------------------------------
+spgpuMmProperties = _decl("spgpuMmProperties", i32, [C.c_char_p, ptr])
+spgpuMmReadCoo = _decl("spgpuMmReadCoo", i32, [C.c_char_p, C.c_char, ptr, ptr, ptr])
+spgpuMmUnfoldedSizeD = _decl("spgpuMmUnfoldedSizeD", i32, [ptr, ptr, ptr, i32])
+spgpuMmUnfoldD = _decl("spgpuMmUnfoldD", None, [ptr, ptr, ptr, ptr, ptr, ptr, i32])
+
+
 # ---- device_scalars.h (new: results and coefficients in device memory, graph-capturable) ---------------------
 dot_device, axpby_device, axpby_quot_device, div_device = {}, {}, {}, {}
 for _L in "SD":

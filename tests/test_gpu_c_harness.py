@@ -28,8 +28,39 @@ def test_hellperf_flow(pattern, precision):
     assert "checksums identical: PASSED" in out
 
 
+@pytest.mark.parametrize("precision", ["d", "s"])
+def test_hellperf_on_a_matrix_market_file(tmp_path, precision):
+    """The reference harness's real input path: a symmetric coordinate file (lower triangle stored) is read, unfolded,
+    converted and run through ELL and HELL; and a general rectangular one."""
+    import numpy as np
+    n = 3000
+    rng = np.random.default_rng(5)
+    lower = [(i, j) for i in range(n) for j in {max(0, i - 7), max(0, i - 1), i} if j <= i]
+    lower = sorted(set(lower))
+    sym = tmp_path / "sym.mtx"
+    with open(sym, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% test matrix\n")
+        f.write(f"{n} {n} {len(lower)}\n")
+        for i, j in lower:
+            f.write(f"{i + 1} {j + 1} {rng.standard_normal():.17g}\n")
+    out = _run("hellperf_amd", sym, 5, precision)
+    unfolded = 2 * len(lower) - n
+    assert f"symmetric storage unfolded: {unfolded} entries" in out
+    assert f"{n} rows, {n} columns, {unfolded} nnz" in out and "checksums identical: PASSED" in out
+    rect = tmp_path / "rect.mtx"
+    rows, cols, per_row = 1000, 1700, 4
+    with open(rect, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{rows} {cols} {rows * per_row}\n")
+        for i in range(rows):
+            for j in sorted(rng.choice(cols, per_row, replace=False)):
+                f.write(f"{i + 1} {j + 1} {rng.standard_normal():.17g}\n")
+    out = _run("hellperf_amd", rect, 5, precision)
+    assert f"{rows} rows, {cols} columns, {rows * per_row} nnz" in out and "checksums identical: PASSED" in out
+
+
 def test_cg_converges():
     out = _run("cg_amd", 128, 2000, 1e-10)
-    assert "PASSED" in out
+    assert "PASSED" in out and "bit-identical to the eager run" in out
     last = [l for l in out.splitlines() if "relative residual" in l][-1]
     assert float(last.split("max |x - 1| =")[1]) < 1e-6

@@ -1,12 +1,13 @@
 /*
  * Plain-C performance harness with the flow of the reference's src/tests/hellPerf.cpp:127-317
  * (COO -> computeEllRowLenghts/cooToEll -> ELL run; computeHellAllocSize/ellToHell -> HELL run;
- * per format: 1 warm-up, dot(z,z) printed as checksum, N timed launches, GFlop/s), with a synthetic
- * matrix instead of a Matrix Market file (none ships with the reference) and HIP in place of the
- * CUDA runtime.  alpha = 1, beta = 0 as hellPerf.cpp:27-28.  Adds what the reference's harness
+ * per format: 1 warm-up, dot(z,z) printed as checksum, N timed launches, GFlop/s), on a Matrix Market
+ * file as the reference's harness (symmetric storage unfolded, hellPerf.cpp:93-113) or on a synthetic
+ * matrix (no .mtx ships with the reference), and with HIP in place of the CUDA runtime.  alpha = 1, beta = 0 as hellPerf.cpp:27-28.  Adds what the reference's harness
  * lacks: the two dot(z,z) are compared, and achieved HBM GB/s is printed next to GFlop/s.
  *
  *   usage: hellperf_amd [rows=1000000] [nnzPerRow=32] [banded|random] [reps=200] [s|d]
+ *          hellperf_amd matrix.mtx [reps=200] [s|d]
  */
 #include <math.h>
 #include <stdint.h>
@@ -19,6 +20,7 @@
 #include "spgpu/ell_conv.h"
 #include "spgpu/hell.h"
 #include "spgpu/hell_conv.h"
+#include "spgpu/mmread.h"
 #include "spgpu/vector.h"
 
 #define CHECK(call)                                                                                   \
@@ -39,35 +41,78 @@ static uint64_t splitmix(uint64_t* s)
 }
 static double unit(uint64_t* s) { return (double)(splitmix(s) >> 11) / 9007199254740992.0; }
 
+/* Matrix Market file -> zero-based COO in the requested precision; symmetric storage is mirrored. */
+static int loadMtx(const char* path, int dbl, int* rows, int* cols, long long* nnz, int** cooR, int** cooC, void** cooV)
+{
+    int prop[6];
+    if (!spgpuMmProperties(path, prop)) { fprintf(stderr, "%s: not a readable Matrix Market file\n", path); return 0; }
+    int n = prop[2];
+    int *r = (int*)malloc((size_t)n * sizeof(int)), *c = (int*)malloc((size_t)n * sizeof(int));
+    double* v = (double*)malloc((size_t)n * sizeof(double));
+    const int code = spgpuMmReadCoo(path, 'd', v, r, c);
+    if (code != 0) { fprintf(stderr, "%s: read failed with code %d\n", path, code); return 0; }
+    if (prop[5] == 1 /* MATRIX_TYPE_SYMMETRIC */) {
+        const int total = spgpuMmUnfoldedSizeD(v, r, c, n);
+        int *ur = (int*)malloc((size_t)total * sizeof(int)), *uc = (int*)malloc((size_t)total * sizeof(int));
+        double* uv = (double*)malloc((size_t)total * sizeof(double));
+        spgpuMmUnfoldD(ur, uc, uv, r, c, v, n);
+        free(r); free(c); free(v);
+        r = ur; c = uc; v = uv; n = total;
+        printf("symmetric storage unfolded: %d entries\n", n);
+    }
+    *rows = prop[0]; *cols = prop[1]; *nnz = n; *cooR = r; *cooC = c;
+    if (dbl) {
+        *cooV = v;
+    } else {
+        float* f = (float*)malloc((size_t)n * sizeof(float));
+        for (int e = 0; e < n; ++e) f[e] = (float)v[e];
+        free(v);
+        *cooV = f;
+    }
+    return 1;
+}
+
 int main(int argc, char** argv)
 {
-    const int rows = argc > 1 ? atoi(argv[1]) : 1000000;
-    const int perRow = argc > 2 ? atoi(argv[2]) : 32;
-    const int randomCols = argc > 3 && strcmp(argv[3], "random") == 0;
-    const int reps = argc > 4 ? atoi(argv[4]) : 200;
-    const int dbl = !(argc > 5 && argv[5][0] == 's');
+    const int fromFile = argc > 1 && strstr(argv[1], ".mtx") != NULL;
+    int rows = !fromFile && argc > 1 ? atoi(argv[1]) : 1000000;
+    int cols = rows;
+    int perRow = !fromFile && argc > 2 ? atoi(argv[2]) : 32;
+    const int randomCols = !fromFile && argc > 3 && strcmp(argv[3], "random") == 0;
+    const int reps = fromFile ? (argc > 2 ? atoi(argv[2]) : 200) : (argc > 4 ? atoi(argv[4]) : 200);
+    const char* prec = fromFile ? (argc > 3 ? argv[3] : "d") : (argc > 5 ? argv[5] : "d");
+    const int dbl = prec[0] != 's';
     const size_t es = dbl ? sizeof(double) : sizeof(float);
     const spgpuType_t type = dbl ? SPGPU_TYPE_DOUBLE : SPGPU_TYPE_FLOAT;
     const int hackSize = 32; /* hellPerf.cpp:254 */
-    const long long nnz = (long long)rows * perRow;
+    long long nnz = (long long)rows * perRow;
     if (nnz > 2000000000LL) { fprintf(stderr, "too many nonzeros for int indices\n"); return 2; }
 
-    /* ---- synthetic COO ---- */
-    int* cooR = (int*)malloc(nnz * sizeof(int));
-    int* cooC = (int*)malloc(nnz * sizeof(int));
-    void* cooV = malloc(nnz * es);
+    int *cooR, *cooC;
+    void* cooV;
     uint64_t seed = 1;
-    for (long long e = 0; e < nnz; ++e) {
-        const int r = (int)(e / perRow), k = (int)(e % perRow);
-        cooR[e] = r;
-        cooC[e] = randomCols ? (int)(splitmix(&seed) % (uint64_t)rows)
-                             : (int)(((long long)r + k - perRow / 2 + rows) % rows);
-        if (dbl) ((double*)cooV)[e] = unit(&seed); else ((float*)cooV)[e] = (float)unit(&seed);
+    if (fromFile) {
+        if (!loadMtx(argv[1], dbl, &rows, &cols, &nnz, &cooR, &cooC, &cooV)) return 2;
+        perRow = rows ? (int)(nnz / rows) : 0; /* ellAvgRowSize, hellPerf.cpp:131 */
+    } else {
+        /* ---- synthetic COO ---- */
+        cooR = (int*)malloc(nnz * sizeof(int));
+        cooC = (int*)malloc(nnz * sizeof(int));
+        cooV = malloc(nnz * es);
+        for (long long e = 0; e < nnz; ++e) {
+            const int r = (int)(e / perRow), k = (int)(e % perRow);
+            cooR[e] = r;
+            cooC[e] = randomCols ? (int)(splitmix(&seed) % (uint64_t)rows)
+                                 : (int)(((long long)r + k - perRow / 2 + rows) % rows);
+            if (dbl) ((double*)cooV)[e] = unit(&seed); else ((float*)cooV)[e] = (float)unit(&seed);
+        }
     }
-    void *x = malloc(rows * es), *y = malloc(rows * es);
+    void *x = malloc((size_t)cols * es), *y = malloc((size_t)rows * es);
+    for (int i = 0; i < cols; ++i) {
+        if (dbl) ((double*)x)[i] = unit(&seed); else ((float*)x)[i] = (float)unit(&seed);
+    }
     for (int i = 0; i < rows; ++i) {
-        if (dbl) { ((double*)x)[i] = unit(&seed); ((double*)y)[i] = unit(&seed); }
-        else     { ((float*)x)[i] = (float)unit(&seed); ((float*)y)[i] = (float)unit(&seed); }
+        if (dbl) ((double*)y)[i] = unit(&seed); else ((float*)y)[i] = (float)unit(&seed);
     }
 
     /* ---- COO -> ELL -> HELL on the host (hellPerf.cpp:136-152, 254-264) ---- */
@@ -84,19 +129,19 @@ int main(int argc, char** argv)
     int* hellI = (int*)calloc((size_t)hackSize * height, sizeof(int));
     int* hackOff = (int*)calloc(hacks, sizeof(int));
     ellToHell(hellV, hellI, hackOff, hackSize, ellV, ellI, pitch, pitch, rowLen, rows, type);
-    printf("%d rows, %lld nnz, %s columns, %s | ELL %d x %d (%.1f MB) | HELL height %d (%.1f MB)\n", rows, nnz,
-           randomCols ? "random" : "banded", dbl ? "double" : "float", maxRow, pitch,
+    printf("%d rows, %d columns, %lld nnz, %s, %s | ELL %d x %d (%.1f MB) | HELL height %d (%.1f MB)\n", rows, cols, nnz,
+           fromFile ? argv[1] : (randomCols ? "random columns" : "banded"), dbl ? "double" : "float", maxRow, pitch,
            (double)maxRow * pitch * (es + 4) * 1e-6, height, (double)hackSize * height * (es + 4) * 1e-6);
 
     /* ---- upload (hellPerf.cpp:176-190, 274-280) ---- */
     void *dX, *dY, *dZ, *dEllV, *dHellV;
     int *dRs, *dEllI, *dHellI, *dHack;
-    CHECK(hipMalloc(&dX, rows * es)); CHECK(hipMalloc(&dY, rows * es)); CHECK(hipMalloc(&dZ, rows * es));
+    CHECK(hipMalloc(&dX, (size_t)cols * es)); CHECK(hipMalloc(&dY, rows * es)); CHECK(hipMalloc(&dZ, rows * es));
     CHECK(hipMalloc((void**)&dRs, rows * sizeof(int)));
     CHECK(hipMalloc(&dEllV, (size_t)maxRow * pitch * es)); CHECK(hipMalloc((void**)&dEllI, (size_t)maxRow * pitch * sizeof(int)));
     CHECK(hipMalloc(&dHellV, (size_t)hackSize * height * es)); CHECK(hipMalloc((void**)&dHellI, (size_t)hackSize * height * sizeof(int)));
     CHECK(hipMalloc((void**)&dHack, hacks * sizeof(int)));
-    CHECK(hipMemcpy(dX, x, rows * es, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dY, y, rows * es, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dX, x, (size_t)cols * es, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dY, y, rows * es, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dRs, rowLen, rows * sizeof(int), hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dEllV, ellV, (size_t)maxRow * pitch * es, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dEllI, ellI, (size_t)maxRow * pitch * sizeof(int), hipMemcpyHostToDevice));
@@ -108,7 +153,7 @@ int main(int argc, char** argv)
     if (spgpuCreate(&h, 0) != SPGPU_SUCCESS) return 2;
     hipEvent_t t0, t1;
     CHECK(hipEventCreate(&t0)); CHECK(hipEventCreate(&t1));
-    const double bytes = (double)nnz * (es + 4) + (double)rows * (4 + es) + (double)rows * es;
+    const double bytes = (double)nnz * (es + 4) + (double)rows * (4 + es) + (double)cols * es;
     double dots[2];
 
     for (int format = 0; format < 2; ++format) {
