@@ -319,9 +319,22 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
     new_rows = lambda rows: torch.empty(rows, k, dtype=torch.float64, device=dev)
     needed_mode = split and args.exchange == "needed"
     if needed_mode:
-        # only the X rows A_rest names travel: its columns are renumbered into that sorted list
-        needed, compact = sharded.needed_rows_of(rest["rP"], 0)
-        rest_compact = dict(rest, rP=compact.contiguous())
+        # only the X rows A_rest names travel: its columns are renumbered into that sorted list.  The local part of
+        # the set-up runs first and all ranks agree that it worked before any of them enters the set-up collectives
+        # (otherwise: everyone falls back to the all-gather).
+        try:
+            needed, compact = sharded.needed_rows_of(rest["rP"], 0)
+            rest_compact = dict(rest, rP=compact.contiguous())
+            ready = 1.0
+        except Exception as error:  # noqa: BLE001 - any local failure means "use the other exchange"
+            print(f"rank {rank}: needed-rows set-up failed ({error!r}); falling back to all-gather", file=sys.stderr, flush=True)
+            ready = 0.0
+        if world > 1 or (dist.is_available() and dist.is_initialized()):
+            flag = torch.tensor([ready], device=dev, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ready = float(flag.item())
+        needed_mode = ready > 0.5
+    if needed_mode:
         op = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest_compact, local_product, new_rows, needed=needed)
         op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows)
     else:
