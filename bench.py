@@ -59,20 +59,21 @@ def hell_algorithmic_bytes(nnz, rows, cols, hacks, elem=8, beta_nonzero=False, r
     return matrix + rhs * vectors
 
 
-def committed_traffic(rows, nnz_per_row, pattern):
+def committed_traffic(rows, nnz_per_row, pattern, rhs=None):
     """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE
     and --pmc WRITE_SIZE, separate runs, gfx950 x2 correction on FETCH_SIZE), if they were taken on
-    this workload; None otherwise.  bench.py itself cannot collect counters."""
+    this workload; None otherwise.  bench.py itself cannot collect counters.  rhs: the SpMM workload."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_spmv_pmc.json"))):
+    kind = "spmv" if rhs is None else "spmm"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_bench_{kind}_pmc.json"))):
         try:
             with open(path) as f:
                 d = json.load(f)
         except (OSError, ValueError):
             continue
         w = d.get("workload", dict(rows=10_000_000, nnz_per_row=32, pattern="banded"))
-        if (w.get("rows"), w.get("nnz_per_row"), w.get("pattern")) == (rows, nnz_per_row, pattern):
+        if (w.get("rows"), w.get("nnz_per_row"), w.get("pattern"), w.get("rhs")) == (rows, nnz_per_row, pattern, rhs):
             best = int(d["hbm_traffic_bytes_per_launch"])
     return best
 
@@ -447,7 +448,9 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                         parallelism=f"row partition x{world}, " + ("needed-rows exchange" if needed_mode else "all-gather of X")
                                     + (", own/rest column split (overlap)" if split else "")),
             roofline=dict(bound="hbm", achieved=round(alg / t_compute * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                          frac=round(alg / t_compute * 1e-9 / HBM_PEAK_GBS, 4), traffic=None, kernel="hellSpmmStripKernel<double,2>",
+                          frac=round(alg / t_compute * 1e-9 / HBM_PEAK_GBS, 4),
+                          traffic=None if split else committed_traffic(rows_local, L, args.spmm_pattern, rhs=k),
+                          kernel="hellSpmmStripKernel<double,2>",
                           algorithmic_bytes_per_launch=alg, kernel_ms=round(t_compute * 1e3, 4)),
             spmm=dict(compute_only_ms=round(t_compute * 1e3, 4), allgather_only_ms=round(t_gather * 1e3, 4),
                       compute_only_gflops_total=round(flops_total / t_compute * 1e-9, 1),
