@@ -176,3 +176,51 @@ def test_in_place_sum_leaves_rows_without_entries_untouched(gpu):
     got = dZ.cpu().numpy()
     assert got[empty].tobytes() == Z0[empty].tobytes()
     assert got.tobytes() == O.hell_spmm(hell, X, Z0, 0.5, 1.0, in_place=True).tobytes()
+
+
+def test_spmm_randomized_shapes(gpu):
+    """40 random problems around the strip kernel's branch points: rows longer than the 32 slab columns whose indices
+    stay in registers, windows that fit the LDS tile and windows that do not (per workgroup: both kinds in one matrix),
+    hack sizes 32..128, both index bases, 10..32 right-hand sides, leading dimensions larger than the count."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        letter = "D" if trial % 3 else "S"
+        hs = int(rng.choice([32, 64, 96, 128]))
+        base = int(rng.integers(0, 2))
+        rows = int(rng.integers(1, 1500))
+        cols = int(rng.integers(max(64, rows // 2), 2 * rows + 200))
+        count = int(rng.choice([10, 12, 14, 16, 18, 32]))
+        ld = count + int(rng.choice([0, 2, 6]))
+        max_len = int(rng.choice([3, 20, 40, 90]))
+        lengths = rng.integers(0, max_len + 1, size=rows)
+        half = int(rng.choice([8, 40, 150]))                  # band half-width; some row blocks get scattered columns
+        scattered = rng.random((rows + 255) // 256) < 0.3
+        r_parts, c_parts = [], []
+        for i, n in enumerate(lengths):
+            if n == 0:
+                continue
+            centre = int(i * cols / max(rows, 1))
+            lo, hi = (0, cols) if scattered[i // 256] else (max(0, centre - half), min(cols, centre + half + 1))
+            n = min(int(n), hi - lo)
+            c_parts.append(np.sort(rng.choice(np.arange(lo, hi), size=n, replace=False)))
+            r_parts.append(np.full(n, i))
+        r = np.concatenate(r_parts) if r_parts else np.zeros(0, dtype=np.int64)
+        c = np.concatenate(c_parts) if c_parts else np.zeros(0, dtype=np.int64)
+        v = synth.values_for(letter, 50 + trial, r.size)
+        hell = formats.ell_to_hell(formats.coo_to_ell(rows, r, c, v, ell_base=base), hs)
+        Xp = synth.values_for(letter, 90 + trial, cols * ld).reshape(cols, ld)
+        Yp = synth.values_for(letter, 130 + trial, rows * ld).reshape(rows, ld)
+        mat = formats.DeviceHell(hell)
+        dX, dY = formats.to_device(Xp), formats.to_device(Yp)
+        beta = float(rng.choice([0.0, 1.0, -0.75]))
+        dZ = dY.clone()
+        capi.hellspmm[letter](gpu, _p(dZ), _p(dY), capi.scalar(letter, 0.5), _p(mat.cM), _p(mat.rP), mat.hack_size,
+                              _p(mat.hack_offsets), _p(mat.rS), None, 0, mat.rows, _p(dX), capi.scalar(letter, beta),
+                              mat.base, count, ld, ld)
+        torch.cuda.synchronize()
+        got = dZ.cpu().numpy()
+        want = O.hell_spmm(hell, np.ascontiguousarray(Xp[:, :count]), np.ascontiguousarray(Yp[:, :count]) if beta else None, 0.5, beta)
+        assert got[:, :count].tobytes() == want.tobytes(), (trial, letter, hs, base, rows, cols, count, ld, max_len, half)
+        assert np.array_equal(got[:, count:], Yp[:, count:]), trial
