@@ -224,3 +224,30 @@ def test_spmm_randomized_shapes(gpu):
         want = O.hell_spmm(hell, np.ascontiguousarray(Xp[:, :count]), np.ascontiguousarray(Yp[:, :count]) if beta else None, 0.5, beta)
         assert got[:, :count].tobytes() == want.tobytes(), (trial, letter, hs, base, rows, cols, count, ld, max_len, half)
         assert np.array_equal(got[:, count:], Yp[:, count:]), trial
+
+
+@pytest.mark.parametrize("hs", [8, 48, 80])
+@pytest.mark.parametrize("letter", "SD")
+def test_spmm_hack_sizes_off_the_strip_path(gpu, letter, hs):
+    """hackSize not a multiple of 32: the one-row-per-lane kernels (LDS-tiled for 16 rhs, plain otherwise) take over."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    rng = np.random.default_rng(hs)
+    rows, cols = 777, 900
+    lengths = rng.integers(0, 21, size=rows)                   # a border row has 21 columns to choose from
+    r = np.repeat(np.arange(rows), lengths)
+    c = np.concatenate([np.sort(rng.choice(np.arange(max(0, i - 20), min(cols, i + 21)), size=n, replace=False))
+                        for i, n in enumerate(lengths)])
+    v = synth.values_for(letter, 1, r.size)
+    hell = formats.ell_to_hell(formats.coo_to_ell(rows, r, c, v), hs)
+    mat = formats.DeviceHell(hell)
+    for count in (16, 9, 3):
+        X = synth.values_for(letter, 2, cols * count).reshape(cols, count)
+        Y = synth.values_for(letter, 3, rows * count).reshape(rows, count)
+        dX, dY = formats.to_device(X), formats.to_device(Y)
+        dZ = torch.full_like(dY, float("nan"))
+        capi.hellspmm[letter](gpu, _p(dZ), _p(dY), capi.scalar(letter, 2.0), _p(mat.cM), _p(mat.rP), mat.hack_size,
+                              _p(mat.hack_offsets), _p(mat.rS), None, 0, mat.rows, _p(dX), capi.scalar(letter, 0.25),
+                              mat.base, count, count, count)
+        torch.cuda.synchronize()
+        assert dZ.cpu().numpy().tobytes() == O.hell_spmm(hell, X, Y, 2.0, 0.25).tobytes()
