@@ -460,6 +460,13 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                       allgather_step_ms=round(t_step_allgather * 1e3, 4) if t_step_allgather else None,
                       allgather_step_gflops_total=round(flops_total / t_step_allgather * 1e-9, 1) if t_step_allgather else None),
             parity=parity, cpu_baseline=None)
+        if t_step_allgather:
+            # BASELINE configs[4] word for word (all-gather of the dense X), measured in this same process
+            out["as_named_allgather"] = dict(value=round(flops_total / t_step_allgather * 1e-9, 2), unit="GFLOP/s",
+                                             ms_per_step=round(t_step_allgather * 1e3, 5),
+                                             bytes_received_per_rank=(world - 1) * rows_local * k * 8,
+                                             note="same products, whole X all-gathered per step; `value` above moves only the X rows "
+                                                  "the off-block columns name (DESIGN.md section 6)")
         return out
     return None
 
