@@ -10,7 +10,7 @@
  *   SPGPU_SPMV_VARIANT   ELL/HELL SpMV kernel shape (0 = default, see csrc/ellpack_spmv.hip)
  *   SPGPU_NT_LOADS       0: no non-temporal hint on the coefficient/index streams (default 1)
  *   SPGPU_TAIL_LANES     busy lanes below which a wavefront switches to whole-wave rows (default 16)
- *   SPGPU_HDIA_VARIANT   1: 4 diagonals per stage instead of 8
+ *   SPGPU_HDIA_VARIANT   2: 8 diagonals per stage instead of 4
  *   SPGPU_HDIA_BLOCK     HDIA workgroup size 256 (default) / 512 / 1024
  *   SPGPU_HDIA_NARROW    1: one row per lane even when 16-byte accesses are possible
  *   SPGPU_XCD_ORDER      HDIA: 0 hardware workgroup order (default), n: XCD-contiguous runs of n

@@ -19,7 +19,10 @@
  * barrier, and the summation order per row equals the reference's.
  * The diagonal offsets of a hack are read with one load per diagonal that is
  * the same address for all lanes of the strip's hack (a broadcast out of L1);
- * x is read at offsets[d] + row, i.e. contiguously across the lanes of a hack.
+ * x is read at offsets[d] + row, i.e. contiguously across the lanes of a hack:
+ * the RPL values of a strip are one 16-byte load (element-aligned: an odd
+ * offset shifts it by one element) whenever no strip of the wavefront crosses
+ * an edge of the matrix, element loads otherwise.
  * UNROLL diagonals are in flight per lane before the first multiply-add.
  *
  * Roofline: HBM bandwidth.  Algorithmic bytes: sizeof(T) per stored in-range
@@ -90,24 +93,31 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
     const int* __restrict__ offs = a.offsets + firstDiag;
     const T* __restrict__ x = a.x;
 
-    for (int dBase = 0; dBase < waveDiags; dBase += UNROLL) {
-        /* coefficient loads do not depend on the offsets: issue them first */
-        Pack<T, RPL> v[UNROLL];
-        int off[UNROLL];
+    /* coefficients and offsets of a stage are requested one stage ahead: they depend on nothing the stage before
+     * computes, so they travel while its x values are fetched and used */
+    Pack<T, RPL> v[UNROLL], vNext[UNROLL];
+    int off[UNROLL], offNext[UNROLL];
+    auto fetch = [&](int dBase, Pack<T, RPL>* vv, int* oo) {
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (dBase + u < diags) {
-                v[u] = loadPack<NT, T, RPL>(vals + (long long)(dBase + u) * a.hackSize);
-                off[u] = offs[dBase + u];
+                vv[u] = loadPack<NT, T, RPL>(vals + (long long)(dBase + u) * a.hackSize);
+                oo[u] = offs[dBase + u];
             } else {
 #pragma unroll
                 for (int t = 0; t < RPL; ++t)
-                    v[u].v[t] = zeroOf<T>();
-                off[u] = 0;
+                    vv[u].v[t] = zeroOf<T>();
+                oo[u] = 0;
             }
         }
+    };
+    fetch(0, v, off);
+    for (int dBase = 0; dBase < waveDiags; dBase += UNROLL) {
+        if (dBase + UNROLL < waveDiags) /* wave-uniform */
+            fetch(dBase + UNROLL, vNext, offNext);
         Pack<T, RPL> xv[UNROLL];
         bool use[UNROLL][RPL];
+        bool ragged = false; /* a live diagonal whose strip crosses an edge of the matrix */
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const long long col0 = row0 + off[u];
@@ -116,14 +126,33 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
             for (int t = 0; t < RPL; ++t) {
                 const long long col = col0 + t;
                 use[u][t] = dLive && row0 + t < a.rows && col >= 0 && col < a.cols;
-                xv[u].v[t] = x[use[u][t] ? col : 0];
             }
+            ragged |= dLive && !(stripInside && col0 >= 0 && col0 + RPL <= a.cols);
+        }
+        /* Wavefront-uniform choice (a per-lane one is turned back into element loads by the compiler): when no strip
+         * of the wavefront crosses an edge, the RPL consecutive columns of a strip are ONE 16-byte load -- aligned to
+         * the element size only, an odd offset shifts it by one element. */
+        if (RPL > 1 && a.cols >= RPL && __ballot(ragged) == 0ull) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                xv[u] = loadPackElementAligned<T, RPL>(x + (dBase + u < diags ? row0 + off[u] : 0));
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    xv[u].v[t] = x[use[u][t] ? row0 + off[u] + t : 0];
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
             for (int t = 0; t < RPL; ++t)
                 sum[t] = pick(use[u][t], mulAdd(v[u].v[t], xv[u].v[t], sum[t]), sum[t]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            v[u] = vNext[u];
+            off[u] = offNext[u];
         }
     }
 
@@ -210,19 +239,20 @@ static void hdiaSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     if constexpr (WIDE > 1) {
         if (wideOk) {
             a.wideIO = ((uintptr_t)z % 16 == 0) && ((uintptr_t)y % 16 == 0);
-            /* SPGPU_HDIA_VARIANT (experiments): 1 = 4 diagonals/stage, otherwise 8 (default).  Measured on 512^3
-             * (tools/ab_hdia.py, profiles/): within 1 % of each other; XCD-contiguous block orders and
-             * workgroups of 512/1024 lanes are 2-13 % slower than the hardware order with 256 lanes. */
-            if (tune->hdiaVariant == 1)
-                launchHdia<T, WIDE, 4>(stream, a, nt);
-            else
+            /* 4 diagonals per stage by default: with the strip's x values fetched as one 16-byte load the 8-per-stage
+             * form needs 97 VGPRs (5 wavefronts per SIMD) against 56 (8 wavefronts) and is 15 % slower on 512^3
+             * (tools/ab_hdia.py, profiles/r01d_ab_hdia_wide_x.txt); SPGPU_HDIA_VARIANT=2 selects it.  XCD-contiguous
+             * block orders and workgroups of 512/1024 lanes are 2-13 % slower than the hardware order with 256. */
+            if (tune->hdiaVariant == 2)
                 launchHdia<T, WIDE, 8>(stream, a, nt);
+            else
+                launchHdia<T, WIDE, 4>(stream, a, nt);
             spgpuDebugCheck(handle, "hdiaspmv");
             return;
         }
     }
     a.wideIO = 1;
-    launchHdia<T, 1, 8>(stream, a, nt);
+    launchHdia<T, 1, 4>(stream, a, nt);
     spgpuDebugCheck(handle, "hdiaspmv");
 }
 

@@ -102,6 +102,18 @@ template <bool NT, typename E, int N> __device__ inline Pack<E, N> loadPack(cons
     return out;
 }
 
+/* N consecutive elements at an address that is only element-aligned: still ONE load instruction (global memory
+ * takes 16-byte accesses at any dword address), the compiler just may not assume more than alignof(E). */
+template <typename E, int N> __device__ inline Pack<E, N> loadPackElementAligned(const E* p)
+{
+    using Raw = typename RawBits<sizeof(E) * N>::type;
+    typedef Raw LooseRaw __attribute__((aligned(alignof(E)))); /* the vector type, minus its alignment promise */
+    const Raw raw = *reinterpret_cast<const LooseRaw*>(p);
+    Pack<E, N> out;
+    __builtin_memcpy(&out, &raw, sizeof(out));
+    return out;
+}
+
 template <typename E, int N> __device__ inline void storePack(E* p, const Pack<E, N>& value)
 {
     using Raw = typename RawBits<sizeof(E) * N>::type;

@@ -20,7 +20,7 @@ x, z = synth.device_vector(n, "D", 3), torch.empty(n, dtype=torch.float64, devic
 torch.cuda.synchronize()
 alg = 32 * d["height"] * 8 + d["height"] * 4 + (n // 32 + 1) * 4 + 2 * n * 8
 call = lambda: capi.hdiaspmv["D"](handle, p(z), None, 1.0, p(d["dM"]), p(d["offsets"]), 32, p(d["hack_offsets"]), n, n, p(x), 0.0)
-settings = [(0, 1, 2, b) for b in (256, 512, 1024)] + [(0, 1, 1, 256), (0, 0, 2, 256), (1, 1, 2, 256), (4, 1, 2, 256)]
+settings = [(0, 1, 0, b) for b in (256, 512, 1024)] + [(0, 1, 2, 256), (0, 0, 0, 256), (1, 1, 0, 256), (4, 1, 0, 256)]
 times = {s: [] for s in settings}
 for rnd in range(5):
     for s in settings:
