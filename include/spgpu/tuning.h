@@ -9,6 +9,8 @@
  *
  *   SPGPU_SPMV_VARIANT   ELL/HELL SpMV kernel shape (0 = default, see csrc/ellpack_spmv.hip)
  *   SPGPU_NT_LOADS       0: no non-temporal hint on the coefficient/index streams (default 1)
+ *   SPGPU_X_STRIPS       0: never fetch the x values of a strip of rows with one 16-byte load (default 1: whenever
+ *                        the rows of every strip of a wavefront name consecutive columns)
  *   SPGPU_TAIL_LANES     busy lanes below which a wavefront switches to whole-wave rows (default 16)
  *   SPGPU_HDIA_VARIANT   2: 8 diagonals per stage instead of 4
  *   SPGPU_HDIA_BLOCK     HDIA workgroup size 256 (default) / 512 / 1024

@@ -140,6 +140,7 @@ void spgpuTuningReload(void)
     t.xcdOrder = envInt("SPGPU_XCD_ORDER", 0);
     t.spmmVariant = envInt("SPGPU_SPMM_VARIANT", 0);
     t.l1Blocks = envInt("SPGPU_L1_BLOCKS", 0);
+    t.xStrips = envInt("SPGPU_X_STRIPS", 1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);
 }

@@ -69,6 +69,7 @@ template <typename T> struct SlabArgs {
     long long valStride, idxStride; /* elements between two slab columns */
     int wideIO;   /* y and z are aligned for RPL-wide access */
     int tailLanes; /* TAIL kernels: switch to whole-wave rows when <= this many lanes are busy */
+    int xStrips;   /* consecutive columns of a strip: one 16-byte x load (SPGPU_X_STRIPS, default on) */
 };
 
 constexpr int kBlockThreads = 256;
@@ -180,9 +181,11 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
     /* consume(kBase, stage, between): gathers of the stage, then `between()`, then the multiply-adds.
      * vmcnt retires in issue order: loads issued BEFORE the gathers are waited for together with them,
      * loads issued AFTER them (in `between`) stay in flight while the gathers are consumed. */
+    bool tryStrips = RPL > 1 && XPOLICY == 0 && a.xStrips != 0; /* wavefront-uniform */
     auto consume = [&](int kBase, const Stage& s, auto&& between) {
         T xv[UNROLL][RPL];
         bool use[UNROLL][RPL];
+        bool scattered = false; /* a strip whose RPL rows do not name RPL consecutive columns here */
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = kBase + u * PH + phase;
@@ -190,8 +193,29 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
             for (int t = 0; t < RPL; ++t) {
                 const int col = s.c[u].v[t] - a.baseIndex;
                 use[u][t] = k < len[t] && col >= 0;
-                xv[u][t] = loadX<XPOLICY>(x + (use[u][t] ? col : 0));
+                if (RPL > 1 && tryStrips)
+                    scattered |= !use[u][t] || s.c[u].v[t] != s.c[u].v[0] + t;
             }
+        }
+        /* Stencil and band matrices in natural order: neighbouring rows name neighbouring columns, so the x values of
+         * a strip are consecutive and come with ONE element-aligned 16-byte load instead of RPL gathers.  The choice
+         * is wavefront-uniform (the compiler folds a per-lane one back into element loads). */
+        if (RPL > 1 && tryStrips)
+            tryStrips = __ballot(scattered) == 0ull; /* a wavefront that met scattered columns stops looking */
+        if (RPL > 1 && tryStrips) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const Pack<T, RPL> w = loadPackElementAligned<T, RPL>(x + (s.c[u].v[0] - a.baseIndex));
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    xv[u][t] = w.v[t];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    xv[u][t] = loadX<XPOLICY>(x + (use[u][t] ? s.c[u].v[t] - a.baseIndex : 0));
         }
         between();
 #pragma unroll
@@ -376,6 +400,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
      * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams (default 1). */
     const SpgpuTuning* tune = spgpuTuning();
     a.tailLanes = tune->tailLanes >= 0 ? tune->tailLanes : kTailLanes;
+    a.xStrips = tune->xStrips;
     int variant = tune->spmvVariant;
     const bool nt = tune->ntLoads != 0;
     if (variant < 1 || variant > 24)

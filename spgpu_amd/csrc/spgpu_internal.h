@@ -44,6 +44,7 @@ typedef struct SpgpuTuning {
     int xcdOrder;    /* 0 */
     int spmmVariant; /* 0 */
     int l1Blocks;    /* 0: kernel default */
+    int xStrips;     /* 1 */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);
 

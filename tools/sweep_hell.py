@@ -29,11 +29,13 @@ for pattern in patterns:
     call = lambda: capi.hellspmv[letter](handle, p(z), p(y), one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]),
                                          p(h["rS"]), None, L, rows, p(x), zero, 0)
     variants = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "1,2,3,4").split(",")]
+    # the second knob is SPGPU_NT_LOADS, or SPGPU_X_STRIPS with SWEEP_KNOB=xstrips
+    knob = "SPGPU_X_STRIPS" if os.environ.get("SWEEP_KNOB") == "xstrips" else "SPGPU_NT_LOADS"
     configs = [(v, nt) for v in variants for nt in ([1, 0] if os.environ.get("SWEEP_NT", "both") == "both" else [1])]
     best = {}
     for rnd in range(int(os.environ.get("SWEEP_ROUNDS", 3))):
         for v, nt in configs:
-            os.environ["SPGPU_SPMV_VARIANT"], os.environ["SPGPU_NT_LOADS"] = str(v), str(nt)
+            os.environ["SPGPU_SPMV_VARIANT"], os.environ[knob] = str(v), str(nt)
             capi.spgpuTuningReload()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             with torch.cuda.stream(stream):
@@ -47,7 +49,7 @@ for pattern in patterns:
             best.setdefault((v, nt), []).append(t)
     for (v, nt), ts in sorted(best.items()):
         t = sorted(ts)[len(ts) // 2]
-        print(f"{letter} {pattern:7s} variant={v} nt={nt}  median {t:.4f} ms  min {min(ts):.4f} ms  "
+        print(f"{letter} {pattern:7s} variant={v} {knob[6:].lower()}={nt}  median {t:.4f} ms  min {min(ts):.4f} ms  "
               f"{alg / t * 1e-6:8.1f} GB/s  {alg / t * 1e-6 / 8000:6.1%} of 8 TB/s  {2 * h['nnz'] / t * 1e-6:8.1f} GFLOP/s",
               flush=True)
     del h
