@@ -226,7 +226,7 @@ def run_spmv(args, rank, world):
         roofline=dict(bound="hbm", achieved=round(alg / per_launch * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=round(alg / per_launch * 1e-9 / HBM_PEAK_GBS, 4),
                       traffic=committed_traffic(h["rows"], args.nnz_per_row, args.pattern),
-                      kernel="slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, prefetch after gathers, tail>", algorithmic_bytes_per_launch=alg,
+                      kernel="slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, prefetch after gathers, tail, strip x loads>", algorithmic_bytes_per_launch=alg,
                       kernel_ms=round(per_launch * 1e3, 5)),
     )
 
