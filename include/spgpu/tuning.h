@@ -17,6 +17,7 @@
  *   SPGPU_HDIA_NARROW    1: one row per lane even when 16-byte accesses are possible
  *   SPGPU_XCD_ORDER      HDIA: 0 hardware workgroup order (default), n: XCD-contiguous runs of n
  *   SPGPU_SPMM_VARIANT   SpMM kernel shape (0 = default, see csrc/hell_spmm.hip)
+ *   SPGPU_L1_NT          Level-1 streams non-temporal: 1 always, 0 never, unset: vectors beyond the Infinity Cache
  *   SPGPU_L1_BLOCKS      grid cap of the Level-1 kernels (default 16384)
  *
  * Every setting computes the same values up to the summation order documented

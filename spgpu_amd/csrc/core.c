@@ -141,6 +141,7 @@ void spgpuTuningReload(void)
     t.spmmVariant = envInt("SPGPU_SPMM_VARIANT", 0);
     t.l1Blocks = envInt("SPGPU_L1_BLOCKS", 0);
     t.xStrips = envInt("SPGPU_X_STRIPS", 1);
+    t.l1Nt = envInt("SPGPU_L1_NT", -1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);
 }

@@ -51,7 +51,7 @@ __device__ inline cdouble axpbyOne(cdouble alpha, cdouble x, cdouble beta, cdoub
 
 constexpr int kL1Unroll = 4; /* independent 16-byte accesses in flight per lane */
 
-template <typename T, int VEC, bool HAS_BETA>
+template <typename T, int VEC, bool HAS_BETA, bool NT = false>
 __device__ inline void axpbyBody(T* z, int n, T beta, const T* y, T alpha, const T* x, long long pitch)
 {
     const long long shift = (long long)blockIdx.y * pitch;
@@ -68,9 +68,9 @@ __device__ inline void axpbyBody(T* z, int n, T beta, const T* y, T alpha, const
         for (int u = 0; u < kL1Unroll; ++u) {
             const long long p = base + u * kL1Threads + threadIdx.x;
             if (p < packs) {
-                xv[u] = loadPack<false, T, VEC>(x + p * VEC);
+                xv[u] = loadPack<NT, T, VEC>(x + p * VEC);
                 if constexpr (HAS_BETA)
-                    yv[u] = loadPack<false, T, VEC>(y + p * VEC);
+                    yv[u] = loadPack<NT, T, VEC>(y + p * VEC);
             }
         }
 #pragma unroll
@@ -85,7 +85,7 @@ __device__ inline void axpbyBody(T* z, int n, T beta, const T* y, T alpha, const
                     else
                         out.v[t] = mul(alpha, xv[u].v[t]);
                 }
-                storePack<T, VEC>(z + p * VEC, out);
+                storePackMaybeNT<NT, T, VEC>(z + p * VEC, out);
             }
         }
     }
@@ -99,11 +99,11 @@ __device__ inline void axpbyBody(T* z, int n, T beta, const T* y, T alpha, const
     }
 }
 
-template <typename T, int VEC, bool HAS_BETA>
+template <typename T, int VEC, bool HAS_BETA, bool NT = false>
 __global__ __launch_bounds__(kL1Threads) void axpbyKernel(T* z, int n, T beta, const T* y, T alpha, const T* x,
                                                          long long pitch)
 {
-    axpbyBody<T, VEC, HAS_BETA>(z, n, beta, y, alpha, x, pitch);
+    axpbyBody<T, VEC, HAS_BETA, NT>(z, n, beta, y, alpha, x, pitch);
 }
 
 /* scalars from device memory (include/spgpu/device_scalars.h): the same two bodies, chosen by the value of beta.
@@ -162,11 +162,23 @@ static void axpbyLaunch(spgpuHandle_t handle, ApiT* zApi, int n, ApiT betaApi, A
         blocks = cap > 1 ? cap : 1;
     const dim3 grid((unsigned)blocks, (unsigned)count);
     hipStream_t s = handle->currentStream;
+    /* Vectors larger than the 256 MiB Infinity Cache cannot be found there again by the next kernel: stream them
+     * with the non-temporal hint (measured, n = 1e8: 70-71 % -> 75.5-77 % of the HBM peak, profiles/r01d_level1_nt.txt).
+     * Smaller ones -- the vectors of a solver iteration -- stay cached.  SPGPU_L1_NT = 0 / 1 forces the choice. */
+    const long long streamed = (long long)n * (long long)sizeof(T) * count * (2 + (hasBeta ? 1 : 0));
+    const int ntKnob = spgpuTuning()->l1Nt;
+    const bool nt = z != x && z != y && (ntKnob < 0 ? streamed >= (256ll << 20) : ntKnob != 0);
 
 #define SPGPU_AXPBY_GO(VEC)                                                                               \
     do {                                                                                                  \
-        if (hasBeta)                                                                                      \
+        if (hasBeta && nt)                                                                                \
+            hipLaunchKernelGGL((axpbyKernel<T, VEC, true, true>), grid, dim3(kL1Threads), 0, s, z, n, beta, y,   \
+                               alpha, x, (long long)pitch);                                               \
+        else if (hasBeta)                                                                                 \
             hipLaunchKernelGGL((axpbyKernel<T, VEC, true>), grid, dim3(kL1Threads), 0, s, z, n, beta, y,   \
+                               alpha, x, (long long)pitch);                                               \
+        else if (nt)                                                                                      \
+            hipLaunchKernelGGL((axpbyKernel<T, VEC, false, true>), grid, dim3(kL1Threads), 0, s, z, n, beta, y,  \
                                alpha, x, (long long)pitch);                                               \
         else                                                                                              \
             hipLaunchKernelGGL((axpbyKernel<T, VEC, false>), grid, dim3(kL1Threads), 0, s, z, n, beta, y,  \
@@ -249,7 +261,7 @@ template <int MODE, typename T, typename Acc> __device__ inline Acc accumulate(T
     }
 }
 
-template <typename T, int VEC, int MODE>
+template <typename T, int VEC, int MODE, bool NT = false>
 __global__ __launch_bounds__(kL1Threads) void reduceKernel(typename AccOf<T, MODE>::type* partials, int n, const T* a,
                                                           const T* b, long long pitch)
 {
@@ -272,9 +284,9 @@ __global__ __launch_bounds__(kL1Threads) void reduceKernel(typename AccOf<T, MOD
             const long long p = base + u * kL1Threads + threadIdx.x;
             live[u] = p < packs;
             if (live[u]) {
-                av[u] = loadPack<false, T, VEC>(a + p * VEC);
+                av[u] = loadPack<NT, T, VEC>(a + p * VEC);
                 if constexpr (MODE == kDot)
-                    bv[u] = loadPack<false, T, VEC>(b + p * VEC);
+                    bv[u] = loadPack<NT, T, VEC>(b + p * VEC);
                 else
                     bv[u] = av[u];
             }
@@ -331,7 +343,12 @@ static void reduceVectors(spgpuHandle_t handle, typename AccOf<T, MODE>::type* o
             blocks = cap;
         const dim3 grid((unsigned)blocks, (unsigned)vectors);
 
-        if (wide)
+        const int ntKnob = spgpuTuning()->l1Nt;
+        const long long streamed = (long long)n * (long long)sizeof(T) * vectors * (MODE == kDot ? 2 : 1);
+        if (wide && (ntKnob < 0 ? streamed >= (256ll << 20) : ntKnob != 0))
+            hipLaunchKernelGGL((reduceKernel<T, WIDE, MODE, true>), grid, dim3(kL1Threads), 0, s, dev, n, a0, b0,
+                               (long long)pitch);
+        else if (wide)
             hipLaunchKernelGGL((reduceKernel<T, WIDE, MODE>), grid, dim3(kL1Threads), 0, s, dev, n, a0, b0,
                                (long long)pitch);
         else

@@ -122,6 +122,17 @@ template <typename E, int N> __device__ inline void storePack(E* p, const Pack<E
     *reinterpret_cast<Raw*>(p) = raw;
 }
 
+template <bool NT, typename E, int N> __device__ inline void storePackMaybeNT(E* p, const Pack<E, N>& value)
+{
+    using Raw = typename RawBits<sizeof(E) * N>::type;
+    Raw raw;
+    __builtin_memcpy(&raw, &value, sizeof(raw));
+    if constexpr (NT)
+        __builtin_nontemporal_store(raw, reinterpret_cast<Raw*>(p));
+    else
+        *reinterpret_cast<Raw*>(p) = raw;
+}
+
 /* ---- XCD-aware workgroup order ------------------------------------------------
  * MI355X deals consecutive workgroup ids round-robin over its 8 XCDs (observed dispatch
  * behaviour, MI355X_MICROARCH.md; used for speed only, never for correctness), and every

@@ -45,6 +45,7 @@ typedef struct SpgpuTuning {
     int spmmVariant; /* 0 */
     int l1Blocks;    /* 0: kernel default */
     int xStrips;     /* 1 */
+    int l1Nt;        /* -1: by size */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);
 
