@@ -13,7 +13,7 @@
  *                        the rows of every strip of a wavefront name consecutive columns)
  *   SPGPU_TAIL_LANES     busy lanes below which a wavefront switches to whole-wave rows (default 16)
  *   SPGPU_HDIA_VARIANT   2: 8 diagonals per stage instead of 4
- *   SPGPU_HDIA_BLOCK     HDIA workgroup size 256 (default) / 512 / 1024
+ *   SPGPU_HDIA_BLOCK     HDIA workgroup size 256 / 512 (default) / 1024
  *   SPGPU_HDIA_NARROW    1: one row per lane even when 16-byte accesses are possible
  *   SPGPU_XCD_ORDER      HDIA: 0 hardware workgroup order (default), n: XCD-contiguous runs of n
  *   SPGPU_SPMM_VARIANT   SpMM kernel shape (0 = default, see csrc/hell_spmm.hip)

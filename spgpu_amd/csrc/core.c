@@ -135,7 +135,7 @@ void spgpuTuningReload(void)
     t.ntLoads = envInt("SPGPU_NT_LOADS", 1);
     t.tailLanes = envInt("SPGPU_TAIL_LANES", -1);
     t.hdiaVariant = envInt("SPGPU_HDIA_VARIANT", 0);
-    t.hdiaBlock = envInt("SPGPU_HDIA_BLOCK", 256);
+    t.hdiaBlock = envInt("SPGPU_HDIA_BLOCK", 512);
     t.hdiaNarrow = envInt("SPGPU_HDIA_NARROW", 0);
     t.xcdOrder = envInt("SPGPU_XCD_ORDER", 0);
     t.spmmVariant = envInt("SPGPU_SPMM_VARIANT", 0);

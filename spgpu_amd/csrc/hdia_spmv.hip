@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
             for (int t = 0; t < RPL; ++t)
                 out.v[t] = epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
         }
-        storePack<T, RPL>(a.z + row0, out);
+        storePackMaybeNT<NT, T, RPL>(a.z + row0, out); /* z is written once and not read again by this call */
     } else {
 #pragma unroll
         for (int t = 0; t < RPL; ++t) {
@@ -197,14 +197,14 @@ static void launchHdiaSized(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
 template <typename T, int RPL, int UNROLL>
 static void launchHdia(hipStream_t stream, const HdiaArgs<T>& a, bool nt)
 {
-    /* SPGPU_HDIA_BLOCK (experiments): workgroup size 256 (default) / 512 / 1024 */
+    /* SPGPU_HDIA_BLOCK: workgroup size 256 / 512 (default: +3-4 % over 256 on 512^3 with the current kernel) / 1024 */
     const int block = spgpuTuning()->hdiaBlock;
     if (block == 1024)
         launchHdiaSized<T, RPL, UNROLL, 1024>(stream, a, nt);
-    else if (block == 512)
-        launchHdiaSized<T, RPL, UNROLL, 512>(stream, a, nt);
-    else
+    else if (block == 256)
         launchHdiaSized<T, RPL, UNROLL, 256>(stream, a, nt);
+    else
+        launchHdiaSized<T, RPL, UNROLL, 512>(stream, a, nt);
 }
 
 template <typename T, typename ApiT>

@@ -39,7 +39,7 @@ typedef struct SpgpuTuning {
     int ntLoads;     /* 1 */
     int tailLanes;   /* -1: kernel default */
     int hdiaVariant; /* 0 */
-    int hdiaBlock;   /* 256 */
+    int hdiaBlock;   /* 512 */
     int hdiaNarrow;  /* 0 */
     int xcdOrder;    /* 0 */
     int spmmVariant; /* 0 */

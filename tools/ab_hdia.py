@@ -21,6 +21,8 @@ torch.cuda.synchronize()
 alg = 32 * d["height"] * 8 + d["height"] * 4 + (n // 32 + 1) * 4 + 2 * n * 8
 call = lambda: capi.hdiaspmv["D"](handle, p(z), None, 1.0, p(d["dM"]), p(d["offsets"]), 32, p(d["hack_offsets"]), n, n, p(x), 0.0)
 settings = [(0, 1, 0, b) for b in (256, 512, 1024)] + [(0, 1, 2, 256), (0, 0, 0, 256), (1, 1, 0, 256), (4, 1, 0, 256)]
+if os.environ.get("SETTINGS"):   # "xcd,nt,variant,block;..." overrides the default list
+    settings = [tuple(int(v) for v in one.split(",")) for one in os.environ["SETTINGS"].split(";")]
 times = {s: [] for s in settings}
 for rnd in range(5):
     for s in settings:
