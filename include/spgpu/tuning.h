@@ -9,8 +9,9 @@
  *
  *   SPGPU_SPMV_VARIANT   ELL/HELL SpMV kernel shape (0 = default, see csrc/ellpack_spmv.hip)
  *   SPGPU_NT_LOADS       0: no non-temporal hint on the coefficient/index streams (default 1)
- *   SPGPU_X_STRIPS       0: never fetch the x values of a strip of rows with one 16-byte load (default 1: whenever
- *                        the rows of every strip of a wavefront name consecutive columns)
+ *   SPGPU_X_STRIPS       ELL/HELL SpMV: x values of a strip of rows with one 16-byte load where the rows name consecutive
+ *                        columns.  Unset: learnt per matrix from the kernel's own feedback (csrc/ellpack_spmv.hip);
+ *                        1: the strip-capable kernel always; 0: the gather-only kernel always
  *   SPGPU_TAIL_LANES     busy lanes below which a wavefront switches to whole-wave rows (default 16)
  *   SPGPU_HDIA_VARIANT   2: 8 diagonals per stage instead of 4
  *   SPGPU_HDIA_BLOCK     HDIA workgroup size 256 / 512 (default) / 1024

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspgpu.so")
+LIB_PATH = os.environ.get("SPGPU_LIB") or os.path.join(_HERE, "lib", "libspgpu.so")  # SPGPU_LIB: A/B of two builds
 
 
 class MissingNativeLibrary(ImportError):

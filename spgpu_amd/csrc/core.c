@@ -38,11 +38,17 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
         err = hipMalloc(&h->reduceScratch, SPGPU_REDUCE_SCRATCH_BYTES);
     if (err == hipSuccess)
         err = hipHostMalloc(&h->reduceHost, SPGPU_REDUCE_SCRATCH_BYTES, hipHostMallocDefault);
+    if (err == hipSuccess)
+        err = hipHostMalloc((void**)&h->formFeedback, SPGPU_FEEDBACK_ENTRIES * SPGPU_FEEDBACK_SAMPLES * sizeof(int),
+                            hipHostMallocDefault);
+    if (err == hipSuccess)
+        memset(h->formFeedback, 0, SPGPU_FEEDBACK_ENTRIES * SPGPU_FEEDBACK_SAMPLES * sizeof(int));
     hipSetDevice(previous);
 
     if (err != hipSuccess) {
         fprintf(stderr, "spgpuCreate: device %d setup failed: %s\n", device, hipGetErrorString(err));
         if (h->reduceScratch) hipFree(h->reduceScratch);
+        if (h->reduceHost) hipHostFree(h->reduceHost);
         if (h->pub.defaultStream) hipStreamDestroy(h->pub.defaultStream);
         free(h);
         return err == hipErrorOutOfMemory ? SPGPU_OUTOFMEMORY : SPGPU_UNSPECIFIED;
@@ -75,6 +81,7 @@ void spgpuDestroy(spgpuHandle_t pHandle)
     hipStreamSynchronize(h->pub.defaultStream);
     hipFree(h->reduceScratch);
     hipHostFree(h->reduceHost);
+    hipHostFree(h->formFeedback);
     hipStreamDestroy(h->pub.defaultStream);
     hipSetDevice(previous);
     h->magic = 0;
@@ -118,6 +125,21 @@ size_t spgpuSizeOf(spgpuType_t typeCode)
     }
 }
 
+int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    for (unsigned e = 0; e < SPGPU_FEEDBACK_ENTRIES; ++e)
+        if (h->formKey[e] == key && h->formRows[e] == rows)
+            return h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
+    const unsigned e = h->formNext++ % SPGPU_FEEDBACK_ENTRIES; /* oldest entry makes room */
+    h->formKey[e] = key;
+    h->formRows[e] = rows;
+    int* slot = h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
+    for (int i = 0; i < SPGPU_FEEDBACK_SAMPLES; ++i)
+        slot[i] = 0;
+    return slot;
+}
+
 /* ---- tuning knobs (include/spgpu/tuning.h) ---- */
 static SpgpuTuning tuning;
 static int tuningLoaded;
@@ -140,7 +162,7 @@ void spgpuTuningReload(void)
     t.xcdOrder = envInt("SPGPU_XCD_ORDER", 0);
     t.spmmVariant = envInt("SPGPU_SPMM_VARIANT", 0);
     t.l1Blocks = envInt("SPGPU_L1_BLOCKS", 0);
-    t.xStrips = envInt("SPGPU_X_STRIPS", 1);
+    t.xStrips = envInt("SPGPU_X_STRIPS", -1);
     t.l1Nt = envInt("SPGPU_L1_NT", -1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);

@@ -42,6 +42,7 @@
  * [+ 4 for rIdx]; per column: sizeof(T) (x once); per hack: 4.
  */
 #include "numeric.hip.h"
+#include <type_traits>
 #include "spgpu_internal.h"
 
 #include "spgpu/ell.h"
@@ -69,7 +70,7 @@ template <typename T> struct SlabArgs {
     long long valStride, idxStride; /* elements between two slab columns */
     int wideIO;   /* y and z are aligned for RPL-wide access */
     int tailLanes; /* TAIL kernels: switch to whole-wave rows when <= this many lanes are busy */
-    int xStrips;   /* consecutive columns of a strip: one 16-byte x load (SPGPU_X_STRIPS, default on) */
+    int* feedback; /* STRIPS kernels: pinned host ints the sample wavefronts report their form to, or NULL */
 };
 
 constexpr int kBlockThreads = 256;
@@ -105,8 +106,11 @@ template <int POLICY, typename T> __device__ inline T loadX(const T* p)
  *        (PH == 1: a lane walks all entries of its rows, no cross-lane sum)
  * UNROLL slab-column loads issued back to back before the first gather
  * One wavefront owns 64/PH strips = (64/PH)*RPL consecutive rows.
+ * STRIPS compiles the strip-load form in (see consume below); the form without it exists as well because the mere
+ *        presence of the second loop costs the gather loop ~8 % on scattered matrices (measured; same instruction
+ *        counts, so a placement / allocation effect), and the host picks per matrix (launchSlabFamily).
  */
-template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PIPE, bool TAIL, int XPOLICY = 0>
+template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PIPE, bool TAIL, int XPOLICY = 0, bool STRIPS = false>
 __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
@@ -178,44 +182,38 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
             }
         }
     };
-    /* consume(kBase, stage, between): gathers of the stage, then `between()`, then the multiply-adds.
-     * vmcnt retires in issue order: loads issued BEFORE the gathers are waited for together with them,
-     * loads issued AFTER them (in `between`) stay in flight while the gathers are consumed. */
-    bool tryStrips = RPL > 1 && XPOLICY == 0 && a.xStrips != 0; /* wavefront-uniform */
-    auto consume = [&](int kBase, const Stage& s, auto&& between) {
+    /* consume(form, kBase, stage, between): the x values of the stage, then `between()`, then the multiply-adds.
+     * vmcnt retires in issue order: loads issued BEFORE the x loads are waited for together with them,
+     * loads issued AFTER them (in `between`) stay in flight while the x values are consumed.
+     *
+     * Strip form: in a stencil or band matrix in natural order neighbouring rows name neighbouring columns, so the RPL
+     * x values of a strip are consecutive and come with ONE element-aligned 16-byte load instead of RPL gathers.
+     * Whether a stage qualifies is a wavefront-uniform test (stageIsStrips; a per-lane choice is folded back into
+     * element loads by the compiler), and a wavefront that meets scattered columns once stops testing.  The two
+     * forms are separate loops on purpose: joined in one loop body their wait counts have to cover both load
+     * patterns and the gathers end up waited for together with the prefetch (windowed pattern 1.38 -> 1.64 ms). */
+    auto consume = [&](auto stripsTag, int kBase, const Stage& s, auto&& between) {
+        constexpr bool AS_STRIPS = decltype(stripsTag)::value;
         T xv[UNROLL][RPL];
         bool use[UNROLL][RPL];
-        bool scattered = false; /* a strip whose RPL rows do not name RPL consecutive columns here */
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = kBase + u * PH + phase;
-#pragma unroll
-            for (int t = 0; t < RPL; ++t) {
-                const int col = s.c[u].v[t] - a.baseIndex;
-                use[u][t] = k < len[t] && col >= 0;
-                if (RPL > 1 && tryStrips)
-                    scattered |= !use[u][t] || s.c[u].v[t] != s.c[u].v[0] + t;
-            }
-        }
-        /* Stencil and band matrices in natural order: neighbouring rows name neighbouring columns, so the x values of
-         * a strip are consecutive and come with ONE element-aligned 16-byte load instead of RPL gathers.  The choice
-         * is wavefront-uniform (the compiler folds a per-lane one back into element loads). */
-        if (RPL > 1 && tryStrips)
-            tryStrips = __ballot(scattered) == 0ull; /* a wavefront that met scattered columns stops looking */
-        if (RPL > 1 && tryStrips) {
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+            if constexpr (AS_STRIPS) {
                 const Pack<T, RPL> w = loadPackElementAligned<T, RPL>(x + (s.c[u].v[0] - a.baseIndex));
 #pragma unroll
-                for (int t = 0; t < RPL; ++t)
+                for (int t = 0; t < RPL; ++t) {
+                    use[u][t] = true; /* stageIsStrips: every entry of the stage is present */
                     xv[u][t] = w.v[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    const int col = s.c[u].v[t] - a.baseIndex;
+                    use[u][t] = k < len[t] && col >= 0;
+                    xv[u][t] = loadX<XPOLICY>(x + (use[u][t] ? col : 0));
+                }
             }
-        } else {
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-                for (int t = 0; t < RPL; ++t)
-                    xv[u][t] = loadX<XPOLICY>(x + (use[u][t] ? s.c[u].v[t] - a.baseIndex : 0));
         }
         between();
 #pragma unroll
@@ -225,6 +223,17 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
                 sum[t] = pick(use[u][t], mulAdd(s.v[u].v[t], xv[u][t], sum[t]), sum[t]);
             }
         }
+    };
+    auto stageIsStrips = [&](int kBase, const Stage& s) -> bool { /* wavefront-uniform */
+        bool scattered = false;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = kBase + u * PH + phase;
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                scattered |= k >= len[t] || s.c[u].v[0] - a.baseIndex < 0 || s.c[u].v[t] != s.c[u].v[0] + t;
+        }
+        return __ballot(scattered) == 0ull;
     };
 
     constexpr int STEP = PH * UNROLL;
@@ -243,28 +252,56 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
         }
         return false;
     };
+    constexpr bool STRIPS_POSSIBLE = STRIPS && RPL > 1 && XPOLICY == 0;
+    int kBase = 0;
+    bool done = false; /* tail taken */
     if constexpr (PIPE) {
         Stage cur, nxt;
         fetch(0, cur);
-        for (int kBase = 0; kBase < groupLongest; kBase += STEP) {
-            if (switchToTail(kBase))
-                break;
+        /* one stage: `form` says how its x values are fetched */
+        auto stage = [&](auto form) {
             if constexpr (PIPE == 2) {
-                /* prefetch issued after the current gathers: younger in vmcnt order, stays in flight */
-                consume(kBase, cur, [&] { fetch(kBase + STEP, nxt); });
+                /* prefetch issued after the current x loads: younger in vmcnt order, stays in flight */
+                consume(form, kBase, cur, [&] { fetch(kBase + STEP, nxt); });
             } else {
                 fetch(kBase + STEP, nxt); /* lanes past their rows' end fetch nothing */
-                consume(kBase, cur, [] {});
+                consume(form, kBase, cur, [] {});
             }
             cur = nxt;
+        };
+        if constexpr (STRIPS_POSSIBLE) {
+            for (; kBase < groupLongest; kBase += STEP) {
+                if (switchToTail(kBase)) {
+                    done = true;
+                    break;
+                }
+                if (!stageIsStrips(kBase, cur))
+                    break; /* scattered columns: the gather loop takes over from this stage */
+                stage(std::true_type{});
+            }
+            /* three sample wavefronts tell the host which form this matrix runs in (launchSlabFamily) */
+            if (a.feedback) {
+                const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
+                for (int q = 1; q <= 3; ++q)
+                    if (group == groups * q / 4 && lane == 0)
+                        a.feedback[q - 1] = 2 * kBase >= groupLongest ? 2 : 1; /* at least half of it as strips? */
+            }
+        }
+        if (!done) {
+            /* kBase is wavefront-uniform; saying so keeps the loop counter (and every k derived from it) scalar */
+            for (kBase = __builtin_amdgcn_readfirstlane(kBase); kBase < groupLongest; kBase += STEP) {
+                if (switchToTail(kBase))
+                    break;
+                stage(std::false_type{});
+            }
         }
     } else {
-        for (int kBase = 0; kBase < groupLongest; kBase += STEP) {
+        for (; kBase < groupLongest; kBase += STEP) {
             if (switchToTail(kBase))
                 break;
             Stage cur;
             fetch(kBase, cur);
-            consume(kBase, cur, [] {});
+            consume(std::false_type{}, kBase, cur, [] {});
         }
     }
 
@@ -355,17 +392,17 @@ static bool alignedTo(const void* p, size_t bytes)
     return ((uintptr_t)p % bytes) == 0;
 }
 
-template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, int PIPE = 0, bool TAIL = false, int XPOLICY = 0>
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, int PIPE = 0, bool TAIL = false, int XPOLICY = 0, bool STRIPS = false>
 static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
 {
     constexpr int GROUP_ROWS = (kWave / PH) * RPL;
     const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
     const unsigned blocks = (unsigned)((groups + kWavesPerBlock - 1) / kWavesPerBlock);
     if (nt)
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE, TAIL, XPOLICY>), dim3(blocks),
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE, TAIL, XPOLICY, STRIPS>), dim3(blocks),
                            dim3(kBlockThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE, TAIL, XPOLICY>), dim3(blocks),
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE, TAIL, XPOLICY, STRIPS>), dim3(blocks),
                            dim3(kBlockThreads), 0, stream, a);
 }
 
@@ -400,7 +437,6 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
      * SPGPU_NT_LOADS 0/1: non-temporal hint on the coefficient/index streams (default 1). */
     const SpgpuTuning* tune = spgpuTuning();
     a.tailLanes = tune->tailLanes >= 0 ? tune->tailLanes : kTailLanes;
-    a.xStrips = tune->xStrips;
     int variant = tune->spmvVariant;
     const bool nt = tune->ntLoads != 0;
     if (variant < 1 || variant > 24)
@@ -408,6 +444,26 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     const bool narrowVariant = variant == 3 || variant == 4 || (variant >= 13 && variant <= 16);
     if (!wideOk && !narrowVariant)
         variant = 13;
+
+    /* Strip x loads (consume<STRIPS>): which form a matrix runs in is learnt from the kernel itself.  The
+     * strip-capable kernel's sample wavefronts write "ran as strips / as gathers" into pinned host memory; a
+     * later call on the same matrix (same rP, same rows) reads that -- no synchronisation, whatever is there --
+     * and takes the gather-only kernel when at least two of the three samples said gathers.  Both kernels are
+     * correct for every matrix; a stale or missing answer only costs speed.  SPGPU_X_STRIPS = 0 / 1 fixes the form. */
+    bool strips = false;
+    a.feedback = nullptr;
+    if (!narrowVariant && WIDE > 1) {
+        if (tune->xStrips >= 0) {
+            strips = tune->xStrips != 0;
+        } else {
+            int* seen = spgpuFormFeedback(handle, a.rP, a.rows);
+            int gathers = 0;
+            for (int q = 0; q < 3; ++q)
+                gathers += ((volatile int*)seen)[q] == 1 ? 1 : 0;
+            strips = gathers < 2;
+            a.feedback = strips ? seen : nullptr;
+        }
+    }
 
     if (!narrowVariant) {
         a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
@@ -430,9 +486,19 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
 #endif
             case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
             case 17: launchSlab<T, WIDE, 1, IS_HELL, 8, 1, true>(stream, a, nt); break;
-            case 22: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true>(stream, a, nt); break;
+            case 22:
+                if (strips)
+                    launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true, 0, true>(stream, a, nt);
+                else
+                    launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true>(stream, a, nt);
+                break;
             case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;
-            default: launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true>(stream, a, nt); break; /* 21 */
+            default: /* 21 */
+                if (strips)
+                    launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true, 0, true>(stream, a, nt);
+                else
+                    launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true>(stream, a, nt);
+                break;
             }
             return;
         }

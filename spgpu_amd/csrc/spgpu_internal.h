@@ -20,7 +20,16 @@ typedef struct SpgpuPrivateHandle {
     unsigned magic;
     void* reduceScratch; /* device, SPGPU_REDUCE_SCRATCH_BYTES */
     void* reduceHost;    /* pinned host mirror of reduceScratch */
+    /* ELL/HELL SpMV, kernel-form feedback (ellpack_spmv.hip): per recently seen matrix, SPGPU_FEEDBACK_SAMPLES ints
+     * in pinned host memory that sample wavefronts of the strip-capable kernel write (0 unknown, 1 ran as gathers,
+     * 2 ran as strips) and the host reads -- without synchronising -- at a later call on the same matrix. */
+    int* formFeedback;                              /* pinned, SPGPU_FEEDBACK_ENTRIES * SPGPU_FEEDBACK_SAMPLES ints */
+    const void* formKey[8];
+    int formRows[8];
+    unsigned formNext;
 } SpgpuPrivateHandle;
+#define SPGPU_FEEDBACK_ENTRIES 8
+#define SPGPU_FEEDBACK_SAMPLES 4
 
 static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
 {
@@ -33,6 +42,9 @@ static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
  * caller's own hipGetLastError(), again as in the reference. */
 void spgpuDebugCheck(spgpuHandle_t h, const char* what);
 
+/* The feedback ints of the matrix identified by (key, rows): found or newly assigned (and zeroed). */
+int* spgpuFormFeedback(spgpuHandle_t h, const void* key, int rows);
+
 /* Environment knobs (include/spgpu/tuning.h), read once and cached: no getenv in a launch path. */
 typedef struct SpgpuTuning {
     int spmvVariant; /* 0 */
@@ -44,7 +56,7 @@ typedef struct SpgpuTuning {
     int xcdOrder;    /* 0 */
     int spmmVariant; /* 0 */
     int l1Blocks;    /* 0: kernel default */
-    int xStrips;     /* 1 */
+    int xStrips;     /* -1: by feedback */
     int l1Nt;        /* -1: by size */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);

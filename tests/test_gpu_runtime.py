@@ -97,3 +97,37 @@ def test_unusual_hack_sizes(gpu, hs):
     formats.DeviceHell(hell).spmv(gpu, dz, dy, 1.0, dx, 0.5)
     torch.cuda.synchronize()
     assert dz.cpu().numpy().tobytes() == O.default_spmv(hell, x, y, 1.0, 0.5).tobytes()
+
+
+@pytest.mark.parametrize("letter", "SDC")
+def test_strip_and_gather_forms_agree_and_the_choice_is_learnt(gpu, letter, tuning):
+    """ELL/HELL SpMV has a strip-load form (rows naming consecutive columns) and a gather form; by default the library
+    learns per matrix, from its own kernel's feedback, which one to launch.  Whatever it launches -- first call, later
+    calls, either form forced -- the result is the same bits (same order of additions), on a band matrix and on a
+    scattered one."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    rows = 40_000
+    for kind in ("banded", "scattered"):
+        if kind == "banded":
+            n, m, r, c, v = synth.banded_coo(rows, 6, letter, seed=3)
+        else:
+            n, m, r, c, v = synth.random_rows_coo(rows, rows, synth.power_law_lengths(rows, 9.0, 60, seed=4), seed=5, letter=letter)
+        hell = formats.ell_to_hell(formats.coo_to_ell(n, r, c, v), 32)
+        x, y = synth.values_for(letter, 6, m), synth.values_for(letter, 7, n)
+        want = O.default_spmv(hell, x, y, 1.5, -0.5).tobytes()
+        mat = formats.DeviceHell(hell)
+        dx, dy = formats.to_device(x), formats.to_device(y)
+        dz = torch.empty_like(dy)
+        results = []
+        for _ in range(4):                       # unknown -> feedback read on the following calls
+            mat.spmv(gpu, dz, dy, 1.5, dx, -0.5)
+            torch.cuda.synchronize()
+            results.append(dz.cpu().numpy().tobytes())
+        for forced in (0, 1):
+            tuning(SPGPU_X_STRIPS=forced)
+            mat.spmv(gpu, dz, dy, 1.5, dx, -0.5)
+            torch.cuda.synchronize()
+            results.append(dz.cpu().numpy().tobytes())
+        tuning(SPGPU_X_STRIPS=-1)
+        assert all(res == want for res in results), kind
