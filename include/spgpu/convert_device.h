@@ -1,6 +1,6 @@
 #pragma once
 /*
- * Device-side format construction: COO -> ELL, COO -> HELL and COO -> HDIA entirely in HBM.
+ * Device-side format construction: COO -> ELL, COO -> HELL, COO -> HDIA and COO -> DIA entirely in HBM.
  * NEW: the reference converts on ONE host thread
  * (ell.c:39-80, hell.c:46-104) and uploads; for the 320 M nonzeros of BASELINE
  * configs[1] that is seconds of CPU time and a 3.8 GB PCIe copy per matrix.
@@ -87,6 +87,27 @@ spgpuStatus_t spgpuCooToHdiaDevice(spgpuHandle_t handle, __device void* hdiaValu
                                    const __device int* cooColsIndices, const __device void* cooValues,
                                    int cooBaseIndex, spgpuType_t valuesType, int allocationHeight,
                                    const __device void* work, __device void* scratch);
+
+/* ---- COO -> DIA ---------------------------------------------------------------------------------------------
+ * Device counterparts of computeDiaDiagonalsCount and coo2dia (dia.c:11-104): offsets = the distinct (column - row)
+ * values ascending, value of an entry at (row - base) + position * valuesPitch, last duplicate wins, `values` zeroed
+ * by the caller.  Unlike the host call the plan needs cooBaseIndex only to validate the entries. */
+size_t spgpuCooDiaWorkBytes(int rowsCount, int columnsCount);
+
+/* Returns the number of stored diagonals in *diagonals (host); synchronises the stream; leaves the diagonal
+ * numbering in `work`.  SPGPU_UNSUPPORTED if an entry lies outside the matrix. */
+spgpuStatus_t spgpuCooDiaPlanDevice(spgpuHandle_t handle, __host int* diagonals, int rowsCount, int columnsCount,
+                                    int nonZerosCount, const __device int* cooRowIndices,
+                                    const __device int* cooColsIndices, int cooBaseIndex, __device void* work);
+
+/* One int per DIA slot (valuesPitch * diagonals). */
+size_t spgpuCooToDiaScratchBytes(int valuesPitch, int diagonals);
+
+spgpuStatus_t spgpuCooToDiaDevice(spgpuHandle_t handle, __device void* values, __device int* offsets, int valuesPitch,
+                                  int diagonals, int rowsCount, int columnsCount, int nonZerosCount,
+                                  const __device int* cooRowIndices, const __device int* cooColsIndices,
+                                  const __device void* cooValues, int cooBaseIndex, spgpuType_t valuesType,
+                                  const __device void* work, __device void* scratch);
 
 #ifdef __cplusplus
 }

@@ -173,6 +173,10 @@ spgpuCooRowLengthsDevice = _decl("spgpuCooRowLengthsDevice", i32, [Handle, ptr, 
 spgpuCooToEllDevice = _decl("spgpuCooToEllDevice", i32, [Handle, ptr, ptr, i32, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, ptr, ptr])
 spgpuHellPlanDevice = _decl("spgpuHellPlanDevice", i32, [Handle, C.POINTER(i32), ptr, i32, i32, ptr, ptr])
 spgpuCooToHellDevice = _decl("spgpuCooToHellDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, ptr, ptr])
+spgpuCooDiaWorkBytes = _decl("spgpuCooDiaWorkBytes", C.c_size_t, [i32, i32])
+spgpuCooDiaPlanDevice = _decl("spgpuCooDiaPlanDevice", i32, [Handle, C.POINTER(i32), i32, i32, i32, ptr, ptr, i32, ptr])
+spgpuCooToDiaScratchBytes = _decl("spgpuCooToDiaScratchBytes", C.c_size_t, [i32, i32])
+spgpuCooToDiaDevice = _decl("spgpuCooToDiaDevice", i32, [Handle, ptr, ptr, i32, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, ptr, ptr])
 spgpuCooHdiaPlanWorkBytes = _decl("spgpuCooHdiaPlanWorkBytes", C.c_size_t, [i32, i32])
 spgpuCooHdiaPlanDevice = _decl("spgpuCooHdiaPlanDevice", i32, [Handle, C.POINTER(i32), ptr, i32, i32, i32, i32, ptr, ptr, i32, ptr])
 spgpuCooToHdiaScratchBytes = _decl("spgpuCooToHdiaScratchBytes", C.c_size_t, [i32, i32])

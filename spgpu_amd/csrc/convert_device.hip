@@ -255,6 +255,57 @@ static spgpuStatus_t place(spgpuHandle_t handle, void* values, int* indices, lon
     return SPGPU_SUCCESS;
 }
 
+/* ---- COO -> DIA ----------------------------------------------------------------------------------------------
+ * Scratch layout (ints): present[span] | slotOf[span] | scanTotals[tiles+2], span = rows + cols - 1 possible diagonals.
+ * present[d] = 1 if some entry has (column - row) = d - (rows - 1); slotOf = its exclusive scan = the position of
+ * that diagonal among the stored ones (ascending offset, as dia.c:70-84). */
+__global__ __launch_bounds__(kCvThreads) void markDiagonalsKernel(int* present, int* misc, int rows, int cols, int nnz,
+                                                                  const int* cooRows, const int* cooCols, int base)
+{
+    const long long stride = (long long)gridDim.x * kCvThreads;
+    for (long long e = (long long)blockIdx.x * kCvThreads + threadIdx.x; e < nnz; e += stride) {
+        const int r = cooRows[e] - base, c = cooCols[e] - base;
+        if (r < 0 || r >= rows || c < 0 || c >= cols)
+            misc[1] = 1;
+        else
+            present[(long long)(rows - 1) + c - r] = 1;
+    }
+}
+
+__global__ __launch_bounds__(kCvThreads) void diaOffsetsKernel(int* offsets, const int* present, const int* slotOf,
+                                                               long long span, int rows)
+{
+    const long long stride = (long long)gridDim.x * kCvThreads;
+    for (long long d = (long long)blockIdx.x * kCvThreads + threadIdx.x; d < span; d += stride)
+        if (present[d])
+            offsets[slotOf[d]] = (int)(d - (rows - 1));
+}
+
+/* owner[slot] = 1 + the largest COO position that maps to the slot (the reference's in-order memcpy: last one wins) */
+__global__ __launch_bounds__(kCvThreads) void diaClaimKernel(int* owner, const int* slotOf, int rows, int pitch, int nnz,
+                                                             const int* cooRows, const int* cooCols, int base)
+{
+    const long long stride = (long long)gridDim.x * kCvThreads;
+    for (long long e = (long long)blockIdx.x * kCvThreads + threadIdx.x; e < nnz; e += stride) {
+        const int r = cooRows[e] - base, c = cooCols[e] - base;
+        atomicMax(&owner[(long long)slotOf[(long long)(rows - 1) + c - r] * pitch + r], (int)e + 1);
+    }
+}
+
+template <typename E>
+__global__ __launch_bounds__(kCvThreads) void diaWriteKernel(E* values, const int* owner, const int* slotOf, int rows, int pitch,
+                                                             int nnz, const int* cooRows, const int* cooCols,
+                                                             const E* cooValues, int base)
+{
+    const long long stride = (long long)gridDim.x * kCvThreads;
+    for (long long e = (long long)blockIdx.x * kCvThreads + threadIdx.x; e < nnz; e += stride) {
+        const int r = cooRows[e] - base, c = cooCols[e] - base;
+        const long long slot = (long long)slotOf[(long long)(rows - 1) + c - r] * pitch + r;
+        if (owner[slot] == (int)e + 1)
+            values[slot] = cooValues[e];
+    }
+}
+
 } // namespace spgpu
 
 using namespace spgpu;
@@ -339,6 +390,94 @@ spgpuStatus_t spgpuCooToHellDevice(spgpuHandle_t handle, void* hellValues, int* 
     const ConvertWork w = carve(work, rowsCount, nonZerosCount);
     return place<true>(handle, hellValues, hellIndices, 0, 0, hackOffsets, hackSize, hellBaseIndex, rowsCount, nonZerosCount,
                        cooRowIndices, cooColsIndices, cooValues, cooBaseIndex, valuesType, w);
+}
+
+/* ---- COO -> DIA (device counterparts of computeDiaDiagonalsCount and coo2dia, dia.c:11-104) ---- */
+static long long diaSpan(int rows, int cols) { return (long long)rows + cols - 1; }
+
+size_t spgpuCooDiaWorkBytes(int rowsCount, int columnsCount)
+{
+    const long long span = diaSpan(rowsCount, columnsCount) > 0 ? diaSpan(rowsCount, columnsCount) : 1;
+    return ((size_t)16 + 2 * (size_t)span + scanBlocks(span) + 2) * sizeof(int);
+}
+
+size_t spgpuCooToDiaScratchBytes(int valuesPitch, int diagonals)
+{
+    const size_t slots = (size_t)(valuesPitch > 0 ? valuesPitch : 0) * (size_t)(diagonals > 0 ? diagonals : 0);
+    return (slots ? slots : 1) * sizeof(int);
+}
+
+spgpuStatus_t spgpuCooDiaPlanDevice(spgpuHandle_t handle, int* diagonals, int rowsCount, int columnsCount,
+                                    int nonZerosCount, const int* cooRowIndices, const int* cooColsIndices,
+                                    int cooBaseIndex, void* work)
+{
+    if (!handle || !diagonals || !work || rowsCount < 0 || columnsCount < 0 || nonZerosCount < 0)
+        return SPGPU_UNSUPPORTED;
+    *diagonals = 0;
+    const long long span = diaSpan(rowsCount, columnsCount);
+    if (span <= 0)
+        return SPGPU_SUCCESS;
+    hipStream_t s = handle->currentStream;
+    int* misc = static_cast<int*>(work);
+    int* present = misc + 16;
+    int* slotOf = present + span;
+    int* totals = slotOf + span;
+    (void)hipMemsetAsync(work, 0, (16 + (size_t)span) * sizeof(int), s);
+    if (nonZerosCount > 0)
+        hipLaunchKernelGGL(markDiagonalsKernel, dim3(gridFor(nonZerosCount)), dim3(kCvThreads), 0, s, present, misc, rowsCount,
+                           columnsCount, nonZerosCount, cooRowIndices, cooColsIndices, cooBaseIndex);
+    exclusiveScan(s, slotOf, present, span, 1, totals);
+    int* host = static_cast<int*>(spgpuPrivate(handle)->reduceHost);
+    (void)hipMemcpyAsync(host, totals + scanBlocks(span), sizeof(int), hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(host + 1, misc + 1, sizeof(int), hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    if (host[1])
+        return SPGPU_UNSUPPORTED; /* an entry outside the matrix */
+    *diagonals = host[0];
+    spgpuDebugCheck(handle, "cooDiaPlanDevice");
+    return SPGPU_SUCCESS;
+}
+
+spgpuStatus_t spgpuCooToDiaDevice(spgpuHandle_t handle, void* values, int* offsets, int valuesPitch, int diagonals,
+                                  int rowsCount, int columnsCount, int nonZerosCount, const int* cooRowIndices,
+                                  const int* cooColsIndices, const void* cooValues, int cooBaseIndex,
+                                  spgpuType_t valuesType, const void* work, void* scratch)
+{
+    if (!handle || !work || !scratch || valuesPitch < rowsCount || diagonals < 0 || nonZerosCount < 0)
+        return SPGPU_UNSUPPORTED;
+    const long long span = diaSpan(rowsCount, columnsCount);
+    if (span <= 0 || diagonals == 0 || nonZerosCount == 0)
+        return SPGPU_SUCCESS;
+    hipStream_t s = handle->currentStream;
+    const int* present = static_cast<const int*>(work) + 16;
+    const int* slotOf = present + span;
+    int* owner = static_cast<int*>(scratch);
+    (void)hipMemsetAsync(owner, 0, spgpuCooToDiaScratchBytes(valuesPitch, diagonals), s);
+    hipLaunchKernelGGL(diaOffsetsKernel, dim3(gridFor(span)), dim3(kCvThreads), 0, s, offsets, present, slotOf, span, rowsCount);
+    const dim3 grid(gridFor(nonZerosCount)), block(kCvThreads);
+    hipLaunchKernelGGL(diaClaimKernel, grid, block, 0, s, owner, slotOf, rowsCount, valuesPitch, nonZerosCount, cooRowIndices,
+                       cooColsIndices, cooBaseIndex);
+    switch (spgpuSizeOf(valuesType)) {
+    case 4:
+        hipLaunchKernelGGL(diaWriteKernel<uint32_t>, grid, block, 0, s, static_cast<uint32_t*>(values), owner, slotOf, rowsCount,
+                           valuesPitch, nonZerosCount, cooRowIndices, cooColsIndices, static_cast<const uint32_t*>(cooValues),
+                           cooBaseIndex);
+        break;
+    case 8:
+        hipLaunchKernelGGL(diaWriteKernel<uint64_t>, grid, block, 0, s, static_cast<uint64_t*>(values), owner, slotOf, rowsCount,
+                           valuesPitch, nonZerosCount, cooRowIndices, cooColsIndices, static_cast<const uint64_t*>(cooValues),
+                           cooBaseIndex);
+        break;
+    case 16:
+        hipLaunchKernelGGL(diaWriteKernel<ulonglong2>, grid, block, 0, s, static_cast<ulonglong2*>(values), owner, slotOf, rowsCount,
+                           valuesPitch, nonZerosCount, cooRowIndices, cooColsIndices, static_cast<const ulonglong2*>(cooValues),
+                           cooBaseIndex);
+        break;
+    default:
+        return SPGPU_UNSUPPORTED;
+    }
+    spgpuDebugCheck(handle, "cooToDiaDevice");
+    return SPGPU_SUCCESS;
 }
 
 } // extern "C"

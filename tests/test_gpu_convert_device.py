@@ -199,3 +199,41 @@ def test_device_hdia_laplacian(gpu):
     st, dev = _device_hdia(gpu, n, n, r, c, v, 0, 32)
     assert st == capi.SPGPU_SUCCESS
     _same(dev, host, ("height", "hack_offsets", "offsets", "values"))
+
+
+# ---- COO -> DIA -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("letter", "SDCZ")
+def test_device_coo_to_dia_matches_host(gpu, letter):
+    """Same diagonal count, offsets and values as computeDiaDiagonalsCount + coo2dia, byte for byte: shuffled COO,
+    duplicates (the last one wins), both index bases, rectangular matrices, partly filled diagonals."""
+    import torch
+    from spgpu_amd import capi, formats
+    rng = np.random.default_rng(500 + ord(letter))
+    for trial in range(8):
+        base = int(rng.integers(0, 2))
+        n_rows = int(rng.integers(1, 2500))
+        n_cols = n_rows if trial % 2 else int(rng.integers(1, 2500))
+        diagonals = np.unique(rng.integers(-n_rows + 1, n_cols, size=int(rng.integers(1, 10))))
+        r, c, v = _diagonal_coo(rng, letter, base, n_rows, n_cols, diagonals, float(rng.choice([1.0, 0.5])), int(rng.integers(0, 40)))
+        host = formats.coo_to_dia(n_rows, n_cols, r, c, v, coo_base=base)
+        nnz = int(r.size)
+        one = lambda a, dt: formats.to_device(a if a.size else np.zeros(1, dt))
+        dr, dc, dv = one(r, np.int32), one(c, np.int32), one(v, v.dtype)
+        work = torch.empty(capi.spgpuCooDiaWorkBytes(n_rows, n_cols), dtype=torch.uint8, device="cuda:0")
+        count = C.c_int(-1)
+        assert capi.spgpuCooDiaPlanDevice(gpu, C.byref(count), n_rows, n_cols, nnz, _p(dr), _p(dc), base, _p(work)) == capi.SPGPU_SUCCESS
+        assert count.value == host["diags"]
+        pitch = capi.computeDiaAllocPitch(n_rows)
+        values = torch.zeros(max(pitch * count.value, 1), dtype=dv.dtype, device="cuda:0")
+        offsets = torch.zeros(max(count.value, 1), dtype=torch.int32, device="cuda:0")
+        scratch = torch.empty(capi.spgpuCooToDiaScratchBytes(pitch, count.value), dtype=torch.uint8, device="cuda:0")
+        assert capi.spgpuCooToDiaDevice(gpu, _p(values), _p(offsets), pitch, count.value, n_rows, n_cols, nnz, _p(dr), _p(dc), _p(dv),
+                                        base, capi.TYPE_CODE[letter], _p(work), _p(scratch)) == capi.SPGPU_SUCCESS
+        torch.cuda.synchronize()
+        assert offsets.cpu().numpy()[:count.value].tobytes() == host["offsets"].tobytes()
+        assert values.cpu().numpy()[:pitch * count.value].tobytes() == host["values"].tobytes()
+    # an entry outside the matrix is reported
+    bad = formats.to_device(np.array([0, 7], dtype=np.int32))
+    work = torch.empty(capi.spgpuCooDiaWorkBytes(5, 5), dtype=torch.uint8, device="cuda:0")
+    count = C.c_int(-1)
+    assert capi.spgpuCooDiaPlanDevice(gpu, C.byref(count), 5, 5, 2, _p(bad), _p(bad), 0, _p(work)) == capi.SPGPU_UNSUPPORTED
