@@ -167,7 +167,7 @@ static void axpbyLaunch(spgpuHandle_t handle, ApiT* zApi, int n, ApiT betaApi, A
      * Smaller ones -- the vectors of a solver iteration -- stay cached.  SPGPU_L1_NT = 0 / 1 forces the choice. */
     const long long streamed = (long long)n * (long long)sizeof(T) * count * (2 + (hasBeta ? 1 : 0));
     const int ntKnob = spgpuTuning()->l1Nt;
-    const bool nt = z != x && z != y && (ntKnob < 0 ? streamed >= (256ll << 20) : ntKnob != 0);
+    const bool nt = (ntKnob < 0 ? streamed >= (256ll << 20) : ntKnob != 0); /* exact aliasing of z is fine: a lane reads its elements before it writes them */
 
 #define SPGPU_AXPBY_GO(VEC)                                                                               \
     do {                                                                                                  \

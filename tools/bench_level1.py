@@ -21,6 +21,7 @@ for letter, dt, es in (("D", torch.float64, 8), ("S", torch.float32, 4)):
     ops = {
         "axpby beta=0 (1R+1W)": (lambda: capi.axpby[letter](h, p(z), n, zero, p(y), one, p(x)), 2 * n * es),
         "axpby beta!=0 (2R+1W)": (lambda: capi.axpby[letter](h, p(z), n, half, p(y), one, p(x)), 3 * n * es),
+        "axpby in place z=y (2R+1W)": (lambda: capi.axpby[letter](h, p(y), n, half, p(y), one, p(x)), 3 * n * es),
         "dot (2R, host sync)": (lambda: capi.dot[letter](h, n, p(x), p(y)), 2 * n * es),
         "nrm2 (1R, host sync)": (lambda: capi.nrm2[letter](h, n, p(x)), n * es),
     }
