@@ -474,7 +474,7 @@ template <int OP, typename T> __device__ inline T mapOne(T alpha, T beta, T x, T
         return mulAdd(alpha, mul(x, y), mul(beta, z));
 }
 
-template <typename T, int VEC, int OP>
+template <typename T, int VEC, int OP, bool NT = false>
 __global__ __launch_bounds__(kL1Threads) void mapKernel(T* out, int n, T alpha, T beta, const T* x, const T* y, const T* z,
                                                        long long pitch, int alphaIsOne)
 {
@@ -494,13 +494,13 @@ __global__ __launch_bounds__(kL1Threads) void mapKernel(T* out, int n, T alpha, 
         for (int u = 0; u < kL1Unroll; ++u) {
             const long long p = base + u * kL1Threads + threadIdx.x;
             if (p < packs) {
-                xv[u] = loadPack<false, T, VEC>(x + p * VEC);
+                xv[u] = loadPack<NT, T, VEC>(x + p * VEC);
                 if constexpr (OP >= kAxy)
-                    yv[u] = loadPack<false, T, VEC>(y + p * VEC);
+                    yv[u] = loadPack<NT, T, VEC>(y + p * VEC);
                 else
                     yv[u] = xv[u];
                 if constexpr (OP == kAxypbz)
-                    zv[u] = loadPack<false, T, VEC>(z + p * VEC);
+                    zv[u] = loadPack<NT, T, VEC>(z + p * VEC);
                 else
                     zv[u] = xv[u];
             }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(kL1Threads) void mapKernel(T* out, int n, T alpha, 
 #pragma unroll
                 for (int t = 0; t < VEC; ++t)
                     o.v[t] = mapOne<OP>(alpha, beta, xv[u].v[t], yv[u].v[t], zv[u].v[t], alphaIsOne != 0);
-                storePack<T, VEC>(out + p * VEC, o);
+                storePackMaybeNT<NT, T, VEC>(out + p * VEC, o);
             }
         }
     }
@@ -551,7 +551,13 @@ static void mapLaunch(spgpuHandle_t handle, ApiT* outApi, int n, ApiT alphaApi, 
         blocks = cap > 1 ? cap : 1;
     const dim3 grid((unsigned)blocks, (unsigned)count);
     hipStream_t s = handle->currentStream;
-    if (wide)
+    /* same rule as axpby: streams beyond the Infinity Cache go non-temporal */
+    const int ntKnob = spgpuTuning()->l1Nt;
+    const long long streamed = (long long)n * (long long)sizeof(T) * count * (OP == kAxypbz ? 4 : OP == kAxy ? 3 : 2);
+    if (wide && (ntKnob < 0 ? streamed >= (256ll << 20) : ntKnob != 0))
+        hipLaunchKernelGGL((mapKernel<T, WIDE, OP, true>), grid, dim3(kL1Threads), 0, s, out, n, alpha, beta, x, y, z,
+                           (long long)pitch, alphaIsOne);
+    else if (wide)
         hipLaunchKernelGGL((mapKernel<T, WIDE, OP>), grid, dim3(kL1Threads), 0, s, out, n, alpha, beta, x, y, z,
                            (long long)pitch, alphaIsOne);
     else
