@@ -257,6 +257,28 @@ def run_spmv(args, rank, world):
                                        frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4),
                                        parity=spot_check_hell(h, x, y, z, 1.0, 0.0))
             out["variants"] = extras
+            # the same banded workload in the other three value types (untimed extras, each checked against the oracle)
+            types = {}
+            for letter, elem in (("S", 4), ("C", 8), ("Z", 16)):
+                del h, step, s2
+                torch.cuda.empty_cache()
+                h = synth.hell_uniform_on_device(args.rows, args.nnz_per_row, "banded", letter, 32, seed=1, device=dev)
+                xt, yt = synth.device_vector(h["cols"], letter, 3, dev), synth.device_vector(h["rows"], letter, 4, dev)
+                zt = torch.empty_like(yt)
+                torch.cuda.synchronize()
+                pt = lambda t: C.c_void_p(t.data_ptr())
+                at = (handle, pt(zt), pt(yt), capi.scalar(letter, 1.0), pt(h["cM"]), pt(h["rP"]), 32, pt(h["hack_offsets"]),
+                      pt(h["rS"]), None, args.nnz_per_row, h["rows"], pt(xt), capi.scalar(letter, 0.0), 0)
+                step = s2 = lambda at=at, letter=letter: capi.hellspmv[letter](*at)
+                time_launches(stream, step, 5)
+                t = time_launches(stream, step, 50) / 50
+                bytes_t = hell_algorithmic_bytes(h["nnz"], h["rows"], h["cols"], hacks, elem=elem)
+                flops_t = (2.0 if letter == "S" else 8.0) * h["nnz"]
+                types[letter] = dict(ms=round(t * 1e3, 4), hbm_gbs=round(bytes_t / t * 1e-9, 1),
+                                     frac=round(bytes_t / t * 1e-9 / HBM_PEAK_GBS, 4), gflops=round(flops_t / t * 1e-9, 1),
+                                     parity=spot_check_hell(h, xt, yt, zt, 1.0, 0.0))
+                del xt, yt, zt
+            out["other_types_banded"] = types
             if world == 1:
                 # the N = 1 point of the curve `--gpus N` (N > 1) measures: same sharded SpMM step on one rank
                 del h, step, s2

@@ -287,6 +287,27 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
                         a.feedback[q - 1] = 2 * kBase >= groupLongest ? 2 : 1; /* at least half of it as strips? */
             }
         }
+        else if constexpr (RPL > 1 && XPOLICY == 0) {
+            /* gather-only form: the three sample wavefronts still look at their first stage and report, so that a
+             * different matrix that later lives at the same address is recognised (a call or two late) */
+            if (a.feedback) {
+                const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
+                if (group == groups / 4 || group == groups / 2 || group == groups * 3 / 4) {
+                    /* the same measure the strip-capable kernel reports (stages that qualify before the first
+                     * that does not), from a walk over the indices of its own: three wavefronts, outside the loop */
+                    int asStrips = 0;
+                    for (; asStrips < groupLongest; asStrips += STEP) {
+                        Stage probe;
+                        fetch(asStrips, probe);
+                        if (!stageIsStrips(asStrips, probe))
+                            break;
+                    }
+                    for (int q = 1; q <= 3; ++q)
+                        if (group == groups * q / 4 && lane == 0)
+                            a.feedback[q - 1] = 2 * asStrips >= groupLongest ? 2 : 1;
+                }
+            }
+        }
         if (!done) {
             /* kBase is wavefront-uniform; saying so keeps the loop counter (and every k derived from it) scalar */
             for (kBase = __builtin_amdgcn_readfirstlane(kBase); kBase < groupLongest; kBase += STEP) {
@@ -461,7 +482,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             for (int q = 0; q < 3; ++q)
                 gathers += ((volatile int*)seen)[q] == 1 ? 1 : 0;
             strips = gathers < 2;
-            a.feedback = strips ? seen : nullptr;
+            a.feedback = seen; /* both forms report: the matrix at this address may be another one next time */
         }
     }
 
