@@ -98,6 +98,18 @@ __global__ __launch_bounds__(kHdiaThreads) void hdiaSpmvKernel(const HdiaArgs<T>
     Pack<T, RPL> v[UNROLL], vNext[UNROLL];
     int off[UNROLL], offNext[UNROLL];
     auto fetch = [&](int dBase, Pack<T, RPL>* vv, int* oo) {
+        /* a full stage everywhere in the wavefront: its UNROLL offsets are consecutive ints, one load instead of
+         * UNROLL (element-aligned, like the x strips) */
+        const bool whole = UNROLL == 4 && __ballot(dBase + UNROLL > diags) == 0ull;
+        if (whole) {
+            const Pack<int, 4> o4 = loadPackElementAligned<int, 4>(offs + dBase);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                vv[u] = loadPack<NT, T, RPL>(vals + (long long)(dBase + u) * a.hackSize);
+                oo[u] = o4.v[u & 3];
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (dBase + u < diags) {
