@@ -12,36 +12,24 @@
  */
 #include <stdio.h>
 
-#define MATRIX_READ_SUCCESS       0
-#define MATRIX_READ_UNSUPPORTED   1
-#define MATRIX_READ_INVALID_INPUT 2
+/* return codes of the loaders, value kinds and symmetry classes: the reference's names and numbers (mmread.hpp:15-42) */
+enum { MATRIX_READ_SUCCESS = 0, MATRIX_READ_UNSUPPORTED = 1, MATRIX_READ_INVALID_INPUT = 2 };
+enum { MATRIX_STORAGE_INTEGER = 0, MATRIX_STORAGE_REAL = 1, MATRIX_STORAGE_COMPLEX = 2, MATRIX_STORAGE_PATTERN = 3 };
+enum { MATRIX_TYPE_GENERAL = 0, MATRIX_TYPE_SYMMETRIC = 1, MATRIX_TYPE_SKEW = 2, MATRIX_TYPE_HERMITIAN = 3 };
 
-#define MATRIX_STORAGE_INTEGER 0
-#define MATRIX_STORAGE_REAL    1
-#define MATRIX_STORAGE_COMPLEX 2
-#define MATRIX_STORAGE_PATTERN 3
+/* Banner + size line (mmread.hpp:44-50 / mmread.cpp:15-58).  false for a missing or invalid banner, an object that
+ * is not a matrix, or a combination Matrix Market forbids (array+pattern, real+hermitian, pattern+hermitian/skew:
+ * mmio.c mm_is_valid).  All outputs are written on success. */
+bool loadMmProperties(int* rows, int* cols, int* nnz, bool* sparse, int* storage, int* symmetry, FILE* in);
 
-#define MATRIX_TYPE_GENERAL   0
-#define MATRIX_TYPE_SYMMETRIC 1
-#define MATRIX_TYPE_SKEW      2
-#define MATRIX_TYPE_HERMITIAN 3
+/* `nnz` coordinate entries, zero-based on return (mmread.hpp:52-94 / mmread.cpp:144-222).  One overload per value
+ * kind; the last one reads pattern files. */
+int loadMmMatrixToCoo(float* vals, int* ri, int* ci, int rows, int cols, int nnz, bool sparse, int storage, FILE* in);
+int loadMmMatrixToCoo(double* vals, int* ri, int* ci, int rows, int cols, int nnz, bool sparse, int storage, FILE* in);
+int loadMmMatrixToCoo(int* vals, int* ri, int* ci, int rows, int cols, int nnz, bool sparse, int storage, FILE* in);
+int loadMmMatrixToCoo(int* ri, int* ci, int rows, int cols, int nnz, bool sparse, int storage, FILE* in);
 
-/* reference: mmread.hpp:44-50 / mmread.cpp:15-58.  false for a missing/invalid banner, a non-matrix object or a
- * combination Matrix Market forbids (array+pattern, real+hermitian, pattern+hermitian/skew: mmio.c mm_is_valid). */
-bool loadMmProperties(int* rowsCount, int* columnsCount, int* nonZerosCount, bool* isStoredSparse, int* matrixStorage,
-                      int* matrixType, FILE* file);
-
-/* reference: mmread.hpp:52-94 / mmread.cpp:144-222 */
-int loadMmMatrixToCoo(float* values, int* rowIndices, int* columnIndices, int rowsCount, int columnsCount,
-                      int nonZerosCount, bool isStoredSparse, int matrixStorage, FILE* file);
-int loadMmMatrixToCoo(double* values, int* rowIndices, int* columnIndices, int rowsCount, int columnsCount,
-                      int nonZerosCount, bool isStoredSparse, int matrixStorage, FILE* file);
-int loadMmMatrixToCoo(int* values, int* rowIndices, int* columnIndices, int rowsCount, int columnsCount,
-                      int nonZerosCount, bool isStoredSparse, int matrixStorage, FILE* file);
-int loadMmMatrixToCoo(int* rowIndices, int* columnIndices, int rowsCount, int columnsCount, int nonZerosCount,
-                      bool isStoredSparse, int matrixStorage, FILE* file);
-
-/* reference: mmread.hpp:96-111 / mmread.cpp:225-277: `vectorSize` whitespace-separated values. */
-int loadMmVectorToDenseVector(float* values, int vectorSize, int matrixStorage, FILE* file);
-int loadMmVectorToDenseVector(double* values, int vectorSize, int matrixStorage, FILE* file);
-int loadMmVectorToDenseVector(int* values, int vectorSize, int matrixStorage, FILE* file);
+/* `n` whitespace-separated values of a dense vector file (mmread.hpp:96-111 / mmread.cpp:225-277). */
+int loadMmVectorToDenseVector(float* vals, int n, int storage, FILE* in);
+int loadMmVectorToDenseVector(double* vals, int n, int storage, FILE* in);
+int loadMmVectorToDenseVector(int* vals, int n, int storage, FILE* in);

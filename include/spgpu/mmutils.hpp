@@ -5,33 +5,32 @@
  * dropped, diagonal entries are kept once, off-diagonal entries are emitted as (r,c) followed by (c,r).
  */
 
-/* reference: mmutils.hpp:10-26.  ADDS to *unfoldedNonZerosCount (callers initialise it to 0, hellPerf.cpp:97-99). */
-template <typename T>
-void getUnfoldedMmSymmetricSize(int* unfoldedNonZerosCount, T* value, int* rows, int* cols, int nonZerosCount)
+/* Entries the unfolded matrix will have (mmutils.hpp:10-26).  ADDS to *total: callers start it at 0
+ * (hellPerf.cpp:97-99). */
+template <typename T> void getUnfoldedMmSymmetricSize(int* total, T* vals, int* ri, int* ci, int nnz)
 {
-    int extra = 0;
-    for (int e = 0; e < nonZerosCount; ++e)
-        if (value[e] != 0)
-            extra += rows[e] == cols[e] ? 1 : 2;
-    *unfoldedNonZerosCount += extra;
+    int more = 0;
+    for (int e = 0; e < nnz; ++e) {
+        if (vals[e] == 0)
+            continue;
+        more += ri[e] == ci[e] ? 1 : 2;
+    }
+    *total += more;
 }
 
-/* reference: mmutils.hpp:28-62 */
-template <typename T>
-void unfoldMmSymmetricReal(int* unfoldedRows, int* unfoldedCols, T* unfoldedValues, int* rows, int* cols, T* values,
-                           int nonZerosCount)
+/* The unfolding itself (mmutils.hpp:28-62): (r,c) then, off the diagonal, (c,r) with the same value. */
+template <typename T> void unfoldMmSymmetricReal(int* outRi, int* outCi, T* outVals, int* ri, int* ci, T* vals, int nnz)
 {
-    int out = 0;
-    for (int e = 0; e < nonZerosCount; ++e) {
-        if (!(values[e] != 0))
+    int at = 0;
+    for (int e = 0; e < nnz; ++e) {
+        const T v = vals[e];
+        if (v == 0)
             continue;
-        unfoldedRows[out] = rows[e];
-        unfoldedCols[out] = cols[e];
-        unfoldedValues[out++] = values[e];
-        if (rows[e] != cols[e]) {
-            unfoldedRows[out] = cols[e];
-            unfoldedCols[out] = rows[e];
-            unfoldedValues[out++] = values[e];
-        }
+        outRi[at] = ri[e], outCi[at] = ci[e], outVals[at] = v;
+        ++at;
+        if (ri[e] == ci[e])
+            continue;
+        outRi[at] = ci[e], outCi[at] = ri[e], outVals[at] = v;
+        ++at;
     }
 }
