@@ -11,19 +11,17 @@
 extern "C" {
 #endif
 
-/* reference: dia_conv.h:20-25 / dia.c:11-39.  Number of distinct (column - row) values. */
-int computeDiaDiagonalsCount(int rowsCount, int columnsCount, int nonZerosCount, const int* cooRowIndices,
-                             const int* cooColsIndices);
+/* How many distinct (column - row) values the entries have (dia_conv.h:20-25 / dia.c:11-39). */
+int computeDiaDiagonalsCount(int rows, int cols, int nnz, const int* cooRows, const int* cooCols);
 
-/* reference: dia_conv.h:28-40 / dia.c:41-104.  offsets[] gets the distinct (column - row) values in
- * ascending order; the value of an entry goes to values[(row - cooBaseIndex) + position*valuesPitch].
- * Only real entries are written (callers zero `values` first); duplicates: the last one wins. */
-void coo2dia(void* values, int* offsets, int valuesPitch, int diagonals, int rowsCount, int columnsCount,
-             int nonZerosCount, const int* cooRowIndices, const int* cooColsIndices, const void* cooValues,
-             int cooBaseIndex, spgpuType_t valuesType);
+/* offsets[] receives those values in ascending order; an entry's value goes to
+ * values[(row - cooBase) + position*pitch] (dia_conv.h:28-40 / dia.c:41-104).  Only real entries are written
+ * (callers zero `values` first); of duplicates the last one wins. */
+void coo2dia(void* values, int* offsets, int pitch, int diagonals, int rows, int cols, int nnz, const int* cooRows,
+             const int* cooCols, const void* cooValues, int cooBase, spgpuType_t type);
 
-/* reference: dia_conv.h:43 / dia.c:5-9.  rowsCount rounded up to 32. */
-int computeDiaAllocPitch(int rowsCount);
+/* rows rounded up to a multiple of 32 (dia_conv.h:43 / dia.c:5-9). */
+int computeDiaAllocPitch(int rows);
 
 #ifdef __cplusplus
 }
