@@ -816,12 +816,16 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
             else
                 launchSpmm<T, 16, 1, 2>(stream, a);
         } else if (a.count > 4) {
-            if (pairs)
+            if (strips && variant != 1)
+                /* 6 or 8 right-hand sides: the 16-rhs strip kernel with half of each team idle still beats the
+                 * one-row-per-lane kernel by a third (banded 0.67 vs 1.03 ms, windowed 1.94 vs 2.40 ms) */
+                launchSpmmStrips<T, 2>(stream, a);
+            else if (pairs)
                 launchSpmm<T, 4, 2, 4>(stream, a);
             else
                 launchSpmm<T, 8, 1, 2>(stream, a);
         } else {
-            launchSpmm<T, 4, 1, 4>(stream, a);
+            launchSpmm<T, 4, 1, 4>(stream, a);             /* up to 4: measured equal or better than the strip kernel */
         }
     }
     spgpuDebugCheck(handle, "hellspmm");

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 from spgpu_amd import capi, synth  # noqa: E402
 
-rows, L, k = 5_000_000 // 32 * 32, 32, 16
+rows, L, k = 5_000_000 // 32 * 32, 32, int(os.environ.get("RHS", 16))
 handle = capi.create_handle(0)
 stream = torch.cuda.Stream()
 capi.spgpuSetStream(handle, C.c_void_p(stream.cuda_stream))
