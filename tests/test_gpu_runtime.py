@@ -131,3 +131,36 @@ def test_strip_and_gather_forms_agree_and_the_choice_is_learnt(gpu, letter, tuni
             results.append(dz.cpu().numpy().tobytes())
         tuning(SPGPU_X_STRIPS=-1)
         assert all(res == want for res in results), kind
+
+
+@pytest.mark.parametrize("letter", "SDC")
+def test_strip_form_on_bands_with_holes_ell_and_hell(gpu, letter, tuning):
+    """The strip form's hand-over points: a band matrix in which some rows miss entries (so only some stages of some
+    wavefronts qualify), index base 1, ELL (with and without row sizes) and HELL with hack sizes 32 and 64, beta != 0 --
+    all bit-exact against the oracle with the strip kernel forced."""
+    import torch
+    from spgpu_amd import formats, synth
+    tuning(SPGPU_X_STRIPS=1)
+    rng = np.random.default_rng(ord(letter))
+    rows, half = 20_000, 5
+    i = np.arange(rows)[:, None]
+    c = i + np.arange(-half, half + 1)[None, :]
+    keep = (c >= 0) & (c < rows)
+    holes = rng.random(c.shape) < 0.002            # a few missing entries: the rows behind them shift left in the slab
+    holes[rows // 3: rows // 3 + 300] = False      # ... and a stretch without any
+    keep &= ~holes
+    r = np.broadcast_to(i, c.shape)[keep]
+    cols = c[keep]
+    v = synth.values_for(letter, 21, r.size)
+    x, y = synth.values_for(letter, 22, rows), synth.values_for(letter, 23, rows)
+    ell = formats.coo_to_ell(rows, r, cols, v, ell_base=1)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    dz = torch.empty_like(dy)
+    for hs in (32, 64):
+        hell = formats.ell_to_hell(ell, hs)
+        formats.DeviceHell(hell).spmv(gpu, dz, dy, 0.75, dx, 2.0)
+        torch.cuda.synchronize()
+        assert dz.cpu().numpy().tobytes() == O.default_spmv(hell, x, y, 0.75, 2.0).tobytes()
+    formats.DeviceEll(ell).spmv(gpu, dz, dy, 0.75, dx, 2.0)
+    torch.cuda.synchronize()
+    assert dz.cpu().numpy().tobytes() == O.default_spmv(ell, x, y, 0.75, 2.0).tobytes()
