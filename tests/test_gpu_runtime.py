@@ -136,7 +136,7 @@ def test_strip_and_gather_forms_agree_and_the_choice_is_learnt(gpu, letter, tuni
 @pytest.mark.parametrize("letter", "SDC")
 def test_strip_form_on_bands_with_holes_ell_and_hell(gpu, letter, tuning):
     """The strip form's hand-over points: a band matrix in which some rows miss entries (so only some stages of some
-    wavefronts qualify), index base 1, ELL (with and without row sizes) and HELL with hack sizes 32 and 64, beta != 0 --
+    wavefronts qualify), index base 1, ELL and HELL with hack sizes 32 and 64, beta != 0 --
     all bit-exact against the oracle with the strip kernel forced."""
     import torch
     from spgpu_amd import formats, synth
