@@ -434,10 +434,10 @@ __device__ inline void waveSync()
 
 /* amdgpu_waves_per_eu(3): the LDS footprint admits 3 wavefronts per SIMD; tell the register allocator to stay
  * within the matching 168 VGPRs instead of trading occupancy for scheduling freedom */
-template <typename T, int TRIP>
+template <typename T, int TRIP, int VEC>
 __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) void hellSpmmStripKernel(const SpmmArgs<T> a)
 {
-    constexpr int KP = 8, VEC = 2, TILE_LD = KP * VEC;
+    constexpr int KP = 8, TILE_LD = KP * VEC; /* VEC right-hand sides per lane: 2 (up to 16 in all) or 1 (up to 8) */
     constexpr int ROW_BYTES = TILE_LD * (int)sizeof(T);
     constexpr int CR = 16 / (int)sizeof(T);                     /* rows per coefficient load */
     constexpr int COEF_LOADS = kStageCols * (int)sizeof(T) / 16; /* per stage */
@@ -741,14 +741,14 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
     spmmStore<T, KP, VEC>(a, lane, groupRow0, sum);
 }
 
-template <typename T, int TRIP> static void launchSpmmStrips(hipStream_t stream, const SpmmArgs<T>& in)
+template <typename T, int TRIP, int VEC = 2> static void launchSpmmStrips(hipStream_t stream, const SpmmArgs<T>& in)
 {
     SpmmArgs<T> a = in;
     const long long groups = ((long long)a.rows + kWave - 1) / kWave;
     const unsigned blocks = (unsigned)((groups + kSpmmThreads / kWave - 1) / (kSpmmThreads / kWave));
-    a.tileRows = kStripTileBytes / (16 * (int)sizeof(T));
+    a.tileRows = kStripTileBytes / (8 * VEC * (int)sizeof(T));
     const size_t lds = kStripTileBytes + (kSpmmThreads / kWave) * sizeof(SpmmStage<T>);
-    hipLaunchKernelGGL((hellSpmmStripKernel<T, TRIP>), dim3(blocks), dim3(kSpmmThreads), lds, stream, a);
+    hipLaunchKernelGGL((hellSpmmStripKernel<T, TRIP, VEC>), dim3(blocks), dim3(kSpmmThreads), lds, stream, a);
 }
 
 template <typename T, int KP, int VEC, int UNROLL, bool TILED = false>
@@ -816,10 +816,13 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
             else
                 launchSpmm<T, 16, 1, 2>(stream, a);
         } else if (a.count > 4) {
-            if (strips && variant != 1)
-                /* 6 or 8 right-hand sides: the 16-rhs strip kernel with half of each team idle still beats the
-                 * one-row-per-lane kernel by a third (banded 0.67 vs 1.03 ms, windowed 1.94 vs 2.40 ms) */
-                launchSpmmStrips<T, 2>(stream, a);
+            /* 5 to 8 right-hand sides: the strip kernel with one per lane (64-byte X rows for fp64; no pairing, so odd
+             * counts and odd leading dimensions too) */
+            const bool strips1 = hackSize % 32 == 0 && (uintptr_t)cM % 16 == 0 && (uintptr_t)rP % 16 == 0;
+            if (strips1 && variant == 9 && pairs)
+                launchSpmmStrips<T, 2>(stream, a);          /* experiment: the 16-rhs form with half of each team idle */
+            else if (strips1 && variant != 1)
+                launchSpmmStrips<T, 2, 1>(stream, a);
             else if (pairs)
                 launchSpmm<T, 4, 2, 4>(stream, a);
             else

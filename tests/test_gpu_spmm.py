@@ -120,7 +120,8 @@ def test_own_rest_column_split_reproduces_the_block(gpu, pattern):
 
 
 @pytest.mark.parametrize("letter,hs,count,base", [("D", 32, 16, 0), ("D", 64, 12, 1), ("D", 96, 16, 1), ("S", 32, 16, 1),
-                                                  ("S", 64, 10, 0), ("D", 32, 32, 0), ("D", 32, 8, 0), ("S", 64, 6, 1)])
+                                                  ("S", 64, 10, 0), ("D", 32, 32, 0), ("D", 32, 8, 0), ("S", 64, 6, 1),
+                                                  ("D", 96, 7, 1), ("S", 32, 5, 0)])
 def test_spmm_window_tile_with_ragged_rows(gpu, letter, hs, count, base):
     """The LDS-tile path (columns of a workgroup's 256 rows inside a narrow window) on what it has to get right:
     rows of different lengths including empty ones, a last wavefront and a last hack that are partly filled,
