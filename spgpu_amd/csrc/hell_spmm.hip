@@ -828,7 +828,12 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
             else
                 launchSpmm<T, 8, 1, 2>(stream, a);
         } else {
-            launchSpmm<T, 4, 1, 4>(stream, a);             /* up to 4: measured equal or better than the strip kernel */
+            /* 4: the strip kernel with half of each team idle still wins (banded 0.58 vs 0.63 ms, windowed 1.54 vs
+             * 1.72 ms); 1-3: the small-team plain kernel is as fast or faster on scattered columns */
+            if (a.count == 4 && variant != 1 && hackSize % 32 == 0 && (uintptr_t)cM % 16 == 0 && (uintptr_t)rP % 16 == 0)
+                launchSpmmStrips<T, 2, 1>(stream, a);
+            else
+                launchSpmm<T, 4, 1, 4>(stream, a);
         }
     }
     spgpuDebugCheck(handle, "hellspmm");
