@@ -100,6 +100,14 @@ template <int POLICY, typename T> __device__ inline T loadX(const T* p)
     }
 }
 
+/* The wavefronts that report the form they ran in: about the quarter points of the matrix, nudged off them -- grid
+ * problems put their boundary rows (the ones that never qualify) exactly on power-of-two row numbers. */
+__device__ inline long long sampleGroup(long long groups, int q)
+{
+    const long long at = groups * q / 4 + 2 * q + 1;
+    return at < groups ? at : groups - 1;
+}
+
 /*
  * RPL    rows per lane (1, or 16/sizeof(T) with 16-byte loads)
  * PH     phases: lane groups that split the entries of a row by k mod PH
@@ -200,10 +208,13 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
         for (int u = 0; u < UNROLL; ++u) {
             const int k = kBase + u * PH + phase;
             if constexpr (AS_STRIPS) {
-                const Pack<T, RPL> w = loadPackElementAligned<T, RPL>(x + (s.c[u].v[0] - a.baseIndex));
+                /* stageIsStrips: in this slab column the rows of the strip are all present (consecutive columns) or
+                 * all past their end */
+                const bool present = k < len[0];
+                const Pack<T, RPL> w = loadPackElementAligned<T, RPL>(x + (present ? s.c[u].v[0] - a.baseIndex : 0));
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
-                    use[u][t] = true; /* stageIsStrips: every entry of the stage is present */
+                    use[u][t] = present;
                     xv[u][t] = w.v[t];
                 }
             } else {
@@ -229,9 +240,11 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = kBase + u * PH + phase;
+            const bool present = k < len[0];
 #pragma unroll
-            for (int t = 0; t < RPL; ++t)
-                scattered |= k >= len[t] || s.c[u].v[0] - a.baseIndex < 0 || s.c[u].v[t] != s.c[u].v[0] + t;
+            for (int t = 0; t < RPL; ++t) /* all rows of the strip present with consecutive columns, or all absent */
+                scattered |= (k < len[t]) != present ||
+                             (present && (s.c[u].v[0] - a.baseIndex < 0 || s.c[u].v[t] != s.c[u].v[0] + t));
         }
         return __ballot(scattered) == 0ull;
     };
@@ -283,8 +296,11 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
             if (a.feedback) {
                 const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
                 for (int q = 1; q <= 3; ++q)
-                    if (group == groups * q / 4 && lane == 0)
-                        a.feedback[q - 1] = 2 * kBase >= groupLongest ? 2 : 1; /* at least half of it as strips? */
+                    if (group == sampleGroup(groups, q) && lane == 0)
+                        /* at least half of it as strips -- and more than one stage of it: the test costs about a
+                         * third of a stage, which a single stage of strips does not earn back (5-point Laplacian,
+                         * 16.7 M rows: 258 us with it, 251 us as gathers) */
+                        a.feedback[q - 1] = 2 * kBase >= groupLongest && groupLongest > STEP ? 2 : 1;
             }
         }
         else if constexpr (RPL > 1 && XPOLICY == 0) {
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
              * different matrix that later lives at the same address is recognised (a call or two late) */
             if (a.feedback) {
                 const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
-                if (group == groups / 4 || group == groups / 2 || group == groups * 3 / 4) {
+                if (group == sampleGroup(groups, 1) || group == sampleGroup(groups, 2) || group == sampleGroup(groups, 3)) {
                     /* the same measure the strip-capable kernel reports (stages that qualify before the first
                      * that does not), from a walk over the indices of its own: three wavefronts, outside the loop */
                     int asStrips = 0;
@@ -303,8 +319,8 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
                             break;
                     }
                     for (int q = 1; q <= 3; ++q)
-                        if (group == groups * q / 4 && lane == 0)
-                            a.feedback[q - 1] = 2 * asStrips >= groupLongest ? 2 : 1;
+                        if (group == sampleGroup(groups, q) && lane == 0)
+                            a.feedback[q - 1] = 2 * asStrips >= groupLongest && groupLongest > STEP ? 2 : 1;
                 }
             }
         }
