@@ -472,7 +472,7 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
             roofline=dict(bound="hbm", achieved=round(alg / t_compute * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                           frac=round(alg / t_compute * 1e-9 / HBM_PEAK_GBS, 4),
                           traffic=None if split else committed_traffic(rows_local, L, args.spmm_pattern, rhs=k),
-                          kernel="hellSpmmStripKernel<double,2>",
+                          kernel="hellSpmmStripKernel<double, 2, 2>",
                           algorithmic_bytes_per_launch=alg, kernel_ms=round(t_compute * 1e3, 4)),
             spmm=dict(compute_only_ms=round(t_compute * 1e3, 4), allgather_only_ms=round(t_gather * 1e3, 4),
                       compute_only_gflops_total=round(flops_total / t_compute * 1e-9, 1),
