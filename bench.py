@@ -548,10 +548,34 @@ class HostStagedCollectives:
         return None
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a CHILD process
+    (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) before this process has made any GPU call,
+    let the child's rank 0 print the JSON line on the shared stdout, and exit with the child's code.  Nothing is
+    exec'd and this parent never touches the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as s:       # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        # a record that says n_gpus = world while the caller asked for --gpus N would be void: refuse
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # SPGPU_BENCH_FORCE_DIST=1: initialise RCCL and run the collectives even with one rank (rehearsal of the
     # multi-GPU code path on a 1-GPU box)
     force_dist = os.environ.get("SPGPU_BENCH_FORCE_DIST") == "1"
@@ -562,8 +586,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        if not rehearsing() and torch.cuda.device_count() < world:
+            sys.exit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible")
         torch.cuda.set_device(local_device())
         dist.init_process_group("gloo" if rehearsing() else "nccl")
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+        world = dist.get_world_size()
     workload = args.workload if args.workload != "auto" else ("spmv" if world == 1 else "spmm")
     try:
         (run_spmv if workload == "spmv" else run_spmm)(args, rank, world)

@@ -38,3 +38,30 @@ def test_committed_counter_summaries_match_their_workloads():
                 continue
             assert abs(d["average_ns"] * 1e-6 - d["bench_kernel_ms_same_run"]) / d["bench_kernel_ms_same_run"] < 0.05, name
             assert d["hbm_traffic_bytes_per_launch"] == d["hbm_read_bytes_corrected"] + d["hbm_write_bytes"], name
+
+
+def test_gpus_flag_is_honoured_or_refused(monkeypatch):
+    """`--gpus N` must never silently run fewer ranks: with a launcher around it WORLD_SIZE has to equal N, and without one
+    bench.py starts the N ranks itself as a child process (no GPU call, no exec in the parent)."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True,
+                         timeout=120)
+    assert run.returncode != 0 and "WORLD_SIZE=1" in run.stderr
+
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    code = bench.launch_ranks(bench.parse())
+    assert code == 7                                                   # the child's exit code is the parent's
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -31,3 +31,19 @@ def test_two_ranks_on_one_gpu(gpu, exchange, pattern):
     if exchange == "needed":
         assert out["spmm"]["needed_rows_received_per_rank"] == 31        # 16 rows below the block, 15 above (wrapped band)
         assert out["spmm"]["allgather_step_ms"] > 0
+
+
+def test_gpus_two_direct_form(gpu):
+    """`python bench.py --gpus 2` as the driver types it for N = 1 (no launcher around it): bench.py has to start the two
+    ranks itself and the record has to say n_gpus = 2."""
+    env = dict(os.environ, SPGPU_BENCH_BACKEND="gloo")
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(name, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--spmm-rows-per-gpu", "100000"]
+    run = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["rows_total"] == 200000 and "MISMATCH" not in out["parity"]
