@@ -37,6 +37,17 @@ void ellToOell(int* rIdx, void* dstEllValues, int* dstEllIndices, int* dstRs, co
                const int* srcEllIndices, const int* srcRs, int ellValuesPitch, int ellIndicesPitch, int rowsCount,
                spgpuType_t valuesType);
 
+/* NEW (no counterpart in the reference): the order ellToOell computes, on its own and generalised, for callers that
+ * build the ordered matrix themselves (e.g. straight from COO into HELL).  rIdx[i] = original row at position i,
+ * dstRs[i] = its length.
+ *   window <= 0 (or >= rowsCount), longRows <= 0: exactly ellToOell's order.
+ *   window  > 0: rows are sorted inside consecutive windows of `window` rows only, so that position i stays within
+ *                `window` rows of its original place (x and z keep their locality); windows alternate between
+ *                descending and ascending (length, row) order so that rows of similar length meet where two windows meet.
+ *   longRows > 0: rows LONGER than longRows are taken out of their windows and come first, sorted among themselves
+ *                (descending): a handful of very long rows otherwise sets the depth of one hack per window. */
+void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,11 +24,38 @@
  * Every setting computes the same values up to the summation order documented
  * per kernel; the defaults are the measured best on MI355X.
  */
+#include "core.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 void spgpuTuningReload(void);
+
+/*
+ * Per-handle hint: how the ELL/HELL SpMV kernels fetch x (no counterpart in the reference, whose only per-call hint
+ * is avgNnzPerRow, hell.h:45-59).  Every form computes the same values; for one kernel shape the bits are the same
+ * too (the order in which a row's products are added does not depend on the form).
+ *
+ *   AUTO    the library decides per matrix: sample wavefronts of every launch report what they saw (consecutive
+ *           columns in neighbouring rows / columns inside a window that fits an LDS tile / scattered) and the next
+ *           launch on the same arrays uses it.  A first call runs the strip-capable kernel.
+ *   GATHER  one global load per nonzero.
+ *   STRIPS  the x values of a lane's consecutive rows with ONE 16-byte load where those rows name consecutive
+ *           columns (stencil and band matrices in natural order); falls back to gathers stage by stage.
+ *   XTILE   a workgroup copies the slice of x its rows touch into LDS once, coalesced, and gathers from LDS
+ *           (columns near the diagonal but not consecutive; length-sorted rows used through rIdx); entries outside
+ *           the tile are gathered from global memory.
+ *
+ * The hint applies to every later SpMV call on the handle, from any thread; SPGPU_X_STRIPS / SPGPU_X_TILE in the
+ * environment override it.
+ */
+#define SPGPU_SPMV_FORM_AUTO   0
+#define SPGPU_SPMV_FORM_GATHER 1
+#define SPGPU_SPMV_FORM_STRIPS 2
+#define SPGPU_SPMV_FORM_XTILE  3
+void spgpuSetSpmvForm(spgpuHandle_t handle, int form);
+int spgpuGetSpmvForm(spgpuHandle_t handle);
 
 #ifdef __cplusplus
 }

@@ -183,6 +183,14 @@ spgpuCooToHdiaScratchBytes = _decl("spgpuCooToHdiaScratchBytes", C.c_size_t, [i3
 spgpuCooToHdiaDevice = _decl("spgpuCooToHdiaDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, i32, ptr, ptr, ptr, i32, i32, i32, ptr, ptr])
 
 
+# ---- oell_device.h (new: rows ordered by length in HBM) + the host order (ell_conv.h) ----------------------------
+oellOrder = _decl("oellOrder", None, [ptr, ptr, ptr, i32, i32, i32])
+spgpuOellOrderWorkBytes = _decl("spgpuOellOrderWorkBytes", C.c_size_t, [i32])
+spgpuOellOrderDevice = _decl("spgpuOellOrderDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, ptr])
+spgpuEllToOellDevice = _decl("spgpuEllToOellDevice", i32, [Handle, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr])
+spgpuCooPermuteRowsDevice = _decl("spgpuCooPermuteRowsDevice", i32, [Handle, ptr, ptr, i32, ptr, i32, i32, ptr])
+
+
 # ---- mmread.h (C wrappers of the Matrix Market reader) --------------------------------------------------------
 spgpuMmProperties = _decl("spgpuMmProperties", i32, [C.c_char_p, ptr])
 spgpuMmReadCoo = _decl("spgpuMmReadCoo", i32, [C.c_char_p, C.c_char, ptr, ptr, ptr])
@@ -198,6 +206,11 @@ for _L in "SD":
     axpby_quot_device[_L] = _decl(f"spgpu{_L}axpbyQuotDevice", None, [Handle, ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, ptr])
     div_device[_L] = _decl(f"spgpu{_L}divDevice", None, [Handle, ptr, ptr, ptr, i32])
 
+
+# ---- tuning.h: per-handle kernel-form hint ---------------------------------------------------------------------
+FORM_AUTO, FORM_GATHER, FORM_STRIPS, FORM_XTILE = range(4)
+spgpuSetSpmvForm = _decl("spgpuSetSpmvForm", None, [Handle, i32])
+spgpuGetSpmvForm = _decl("spgpuGetSpmvForm", i32, [Handle])
 
 # ---- tuning.h: environment knobs are cached by the library; call after changing one ---------------------------
 spgpuTuningReload = _decl("spgpuTuningReload", None, [])

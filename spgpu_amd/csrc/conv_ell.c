@@ -63,10 +63,59 @@ void cooToEll(void* ellValues, int* ellIndices, int ellValuesPitch, int ellIndic
     free(fill);
 }
 
+/* ---- row order by length ------------------------------------------------------------------------------------
+ * oellOrder (include/spgpu/ell_conv.h): the general form of the order the reference's ellToOell computes.
+ * Rows fall into groups -- group 0: rows longer than longRows (when longRows > 0), group 1 + r / window: the
+ * others (one group when window <= 0) -- and the groups follow each other in ascending number.  Inside a group
+ * rows descend by (length, row) in group 0 and in every other group from the first; the groups in between ascend
+ * by (length, row), so that where two windows meet, rows of similar length meet. */
+typedef struct { unsigned group; int len; int row; } OellKey;
+
+static int oellKeyCompare(const void* pa, const void* pb)
+{
+    const OellKey* a = (const OellKey*)pa;
+    const OellKey* b = (const OellKey*)pb;
+    if (a->group != b->group)
+        return a->group < b->group ? -1 : 1;
+    const int descending = a->group == 0 || (a->group - 1) % 2 == 0;
+    int order = a->len != b->len ? (a->len < b->len ? -1 : 1) : (a->row < b->row ? -1 : (a->row > b->row ? 1 : 0));
+    return descending ? -order : order;
+}
+
+void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows)
+{
+    if (rowsCount <= 0)
+        return;
+    const int whole = (window <= 0 || window >= rowsCount) && longRows <= 0;
+    if (whole && rowsCount == 2) {
+        /* Bit-exact parity with the reference: its merge sort never runs a merge for exactly two
+         * rows (ell.c:131-157: `while (n < sizetomerge*2)` is 2 < 2), so two rows keep their order
+         * whatever their lengths.  Every other size sorts (verified against the reference build
+         * for all sizes up to 400 and several larger ones, tests/test_f3_converters.py). */
+        rIdx[0] = 0; rIdx[1] = 1;
+        dstRs[0] = srcRs[0]; dstRs[1] = srcRs[1];
+        return;
+    }
+    OellKey* keys = (OellKey*)malloc((size_t)rowsCount * sizeof(OellKey));
+    if (!keys)
+        return;
+    for (int r = 0; r < rowsCount; ++r) {
+        keys[r].group = longRows > 0 && srcRs[r] > longRows ? 0u : 1u + (window > 0 ? (unsigned)(r / window) : 0u);
+        keys[r].len = srcRs[r];
+        keys[r].row = r;
+    }
+    qsort(keys, (size_t)rowsCount, sizeof(OellKey), oellKeyCompare); /* keys are distinct: any sort gives one order */
+    for (int i = 0; i < rowsCount; ++i) {
+        rIdx[i] = keys[i].row;
+        dstRs[i] = keys[i].len;
+    }
+    free(keys);
+}
+
 /* ELL -> ordered ELL.  The reference sorts (length, row) pairs with a bottom-up merge sort whose
  * merge takes the RIGHT run on ties (ell.c:85-157): since every merge joins two adjacent index
- * ranges, the result is the unique order "length descending, then original row descending".
- * That order is produced here directly with a counting sort over lengths. */
+ * ranges, the result is the unique order "length descending, then original row descending" --
+ * oellOrder with one window and no long-row group. */
 void ellToOell(int* rIdx, void* dstEllValues, int* dstEllIndices, int* dstRs, const void* srcEllValues,
                const int* srcEllIndices, const int* srcRs, int ellValuesPitch, int ellIndicesPitch, int rowsCount,
                spgpuType_t valuesType)
@@ -74,36 +123,7 @@ void ellToOell(int* rIdx, void* dstEllValues, int* dstEllIndices, int* dstRs, co
     const size_t elem = spgpuSizeOf(valuesType);
     if (rowsCount <= 0)
         return;
-    int longest = 0;
-    for (int r = 0; r < rowsCount; ++r)
-        if (srcRs[r] > longest)
-            longest = srcRs[r];
-    /* firstOf[len] = first output position of rows with that length (longer rows first) */
-    size_t* firstOf = (size_t*)calloc((size_t)longest + 2, sizeof(size_t));
-    if (!firstOf)
-        return;
-    for (int r = 0; r < rowsCount; ++r)
-        firstOf[srcRs[r]] += 1;
-    size_t run = 0;
-    for (int len = longest; len >= 0; --len) {
-        const size_t n = firstOf[len];
-        firstOf[len] = run;
-        run += n;
-    }
-    for (int r = rowsCount - 1; r >= 0; --r) { /* descending row inside a length class */
-        const size_t at = firstOf[srcRs[r]]++;
-        rIdx[at] = r;
-        dstRs[at] = srcRs[r];
-    }
-    free(firstOf);
-    if (rowsCount == 2) {
-        /* Bit-exact parity with the reference: its merge sort never runs a merge for exactly two
-         * rows (ell.c:131-157: `while (n < sizetomerge*2)` is 2 < 2), so two rows keep their order
-         * whatever their lengths.  Every other size sorts (verified against the reference build
-         * for all sizes up to 400 and several larger ones, tests/test_f3_converters.py). */
-        rIdx[0] = 0; rIdx[1] = 1;
-        dstRs[0] = srcRs[0]; dstRs[1] = srcRs[1];
-    }
+    oellOrder(rIdx, dstRs, srcRs, rowsCount, 0, 0);
 
     for (int i = 0; i < rowsCount; ++i) {
         const int src = rIdx[i];

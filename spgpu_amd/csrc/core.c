@@ -8,6 +8,7 @@
 #include "spgpu_internal.h"
 #include "spgpu/tuning.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -65,6 +66,8 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     h->pub.capabilityMajor = prop.major;
     h->pub.capabilityMinor = prop.minor;
     h->magic = SPGPU_HANDLE_MAGIC;
+    pthread_mutex_init(&h->formLock, NULL);
+    h->spmvForm = SPGPU_SPMV_FORM_AUTO;
 
     *pHandle = &h->pub;
     return SPGPU_SUCCESS;
@@ -78,12 +81,16 @@ void spgpuDestroy(spgpuHandle_t pHandle)
     int previous = 0;
     hipGetDevice(&previous);
     hipSetDevice(h->pub.device);
-    hipStreamSynchronize(h->pub.defaultStream);
+    /* Kernels still queued on ANY stream of this device may write the pinned feedback words and read the reduction
+     * scratch (a caller's stream set with spgpuSetStream, a replayed graph): wait for the whole device, not only
+     * for defaultStream, before freeing them.  A graph captured from this handle must not be replayed after this. */
+    hipDeviceSynchronize();
     hipFree(h->reduceScratch);
     hipHostFree(h->reduceHost);
     hipHostFree(h->formFeedback);
     hipStreamDestroy(h->pub.defaultStream);
     hipSetDevice(previous);
+    pthread_mutex_destroy(&h->formLock);
     h->magic = 0;
     free(h);
 }
@@ -127,17 +134,38 @@ size_t spgpuSizeOf(spgpuType_t typeCode)
 
 int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows)
 {
+    /* Two host threads may share a handle (the reference documents one handle per thread, core.h:88-90, but does not
+     * enforce it): the table is searched and re-assigned under a lock.  The words themselves are written by the GPU
+     * and read without synchronisation by design -- any value selects a correct kernel. */
     SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
-    for (unsigned e = 0; e < SPGPU_FEEDBACK_ENTRIES; ++e)
+    pthread_mutex_lock(&h->formLock);
+    int* slot = NULL;
+    for (unsigned e = 0; e < SPGPU_FEEDBACK_ENTRIES && !slot; ++e)
         if (h->formKey[e] == key && h->formRows[e] == rows)
-            return h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
-    const unsigned e = h->formNext++ % SPGPU_FEEDBACK_ENTRIES; /* oldest entry makes room */
-    h->formKey[e] = key;
-    h->formRows[e] = rows;
-    int* slot = h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
-    for (int i = 0; i < SPGPU_FEEDBACK_SAMPLES; ++i)
-        slot[i] = 0;
+            slot = h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
+    if (!slot) {
+        const unsigned e = h->formNext++ % SPGPU_FEEDBACK_ENTRIES; /* oldest entry makes room */
+        h->formKey[e] = key;
+        h->formRows[e] = rows;
+        slot = h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
+        for (int i = 0; i < SPGPU_FEEDBACK_SAMPLES; ++i)
+            slot[i] = 0;
+    }
+    pthread_mutex_unlock(&h->formLock);
     return slot;
+}
+
+/* ---- per-handle kernel-form hint (include/spgpu/tuning.h) ---- */
+void spgpuSetSpmvForm(spgpuHandle_t pHandle, int form)
+{
+    if (form < SPGPU_SPMV_FORM_AUTO || form > SPGPU_SPMV_FORM_XTILE)
+        form = SPGPU_SPMV_FORM_AUTO;
+    __atomic_store_n(&spgpuPrivate(pHandle)->spmvForm, form, __ATOMIC_RELAXED);
+}
+
+int spgpuGetSpmvForm(spgpuHandle_t pHandle)
+{
+    return __atomic_load_n(&spgpuPrivate(pHandle)->spmvForm, __ATOMIC_RELAXED);
 }
 
 /* ---- tuning knobs (include/spgpu/tuning.h) ---- */
@@ -163,6 +191,8 @@ void spgpuTuningReload(void)
     t.spmmVariant = envInt("SPGPU_SPMM_VARIANT", 0);
     t.l1Blocks = envInt("SPGPU_L1_BLOCKS", 0);
     t.xStrips = envInt("SPGPU_X_STRIPS", -1);
+    t.xTile = envInt("SPGPU_X_TILE", -1);
+    t.xTileShape = envInt("SPGPU_X_TILE_SHAPE", 0);
     t.l1Nt = envInt("SPGPU_L1_NT", -1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);

@@ -74,7 +74,6 @@ template <typename T> struct SlabArgs {
 };
 
 constexpr int kBlockThreads = 256;
-constexpr int kWavesPerBlock = kBlockThreads / kWave;
 constexpr int kTailLanes = 16; /* switch to whole-wave row processing when <= this many lanes are busy
                                   (measured flat between 4 and 16 for the 1-phase kernel, worse above) */
 constexpr int kTailUnroll = 4; /* entries per lane in flight in tail mode */
@@ -100,6 +99,19 @@ template <int POLICY, typename T> __device__ inline T loadX(const T* p)
     }
 }
 
+/* Function-scope LDS: only kernels that call this allocate it (the forms without a tile keep 0 bytes of LDS). */
+template <typename E, int N> __device__ inline E* ldsArray()
+{
+    __shared__ __attribute__((aligned(16))) E buffer[N];
+    return buffer;
+}
+
+/* What one wavefront saw of its rows' columns (XTILE probe). */
+struct ColumnProbe {
+    int lowest, highest, rows;
+    long long middles; /* sum over sampled rows of (first + last column) / 2 */
+};
+
 /* The wavefronts that report the form they ran in: about the quarter points of the matrix, nudged off them -- grid
  * problems put their boundary rows (the ones that never qualify) exactly on power-of-two row numbers. */
 __device__ inline long long sampleGroup(long long groups, int q)
@@ -118,17 +130,24 @@ __device__ inline long long sampleGroup(long long groups, int q)
  *        presence of the second loop costs the gather loop ~8 % on scattered matrices (measured; same instruction
  *        counts, so a placement / allocation effect), and the host picks per matrix (launchSlabFamily).
  */
-template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PIPE, bool TAIL, int XPOLICY = 0, bool STRIPS = false>
-__global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T> a)
+template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PIPE, bool TAIL, int XPOLICY = 0, bool STRIPS = false,
+          int BLOCK = kBlockThreads, int TILE_BYTES = 0>
+__global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
     constexpr int GROUP_ROWS = LPC * RPL;   /* rows owned by the wavefront */
+    constexpr int WAVES = BLOCK / kWave;
+    constexpr bool XTILE = TILE_BYTES > 0;  /* the workgroup stages the slice of x its rows touch in LDS */
+    constexpr int TILE_ELEMS = TILE_BYTES / (int)sizeof(T);
 
     const int lane = threadIdx.x & (kWave - 1);
-    const long long group = (long long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const long long group = (long long)blockIdx.x * WAVES + (threadIdx.x >> 6);
     const long long groupRow0 = group * GROUP_ROWS;
-    if (groupRow0 >= a.rows)
-        return; /* whole wavefront leaves together */
+    if constexpr (!XTILE) {
+        if (groupRow0 >= a.rows)
+            return; /* whole wavefront leaves together */
+    }
+    /* XTILE: a wavefront past the last row stays for the workgroup's barriers; all its rows have length 0 */
 
     const int sub = lane % LPC;   /* which RPL-row strip of the group */
     const int phase = lane / LPC; /* which residue class of k */
@@ -165,6 +184,13 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
     const T* __restrict__ vals = a.cM + slab;
     const int* __restrict__ idxs = a.rP + slab;
     const T* __restrict__ x = a.x;
+
+    /* XTILE: x[tileBase .. tileBase + tileCount) lives in `tile` once the prologue below has run */
+    T* tile = nullptr;
+    int tileBase = 0;
+    unsigned tileCount = 0;
+    if constexpr (XTILE)
+        tile = ldsArray<T, TILE_ELEMS>();
 
     /* One stage = UNROLL slab columns per phase: the coefficient/index loads of a stage are
      * issued back to back (fetch), its x gathers and multiply-adds follow (consume).  With
@@ -211,11 +237,35 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
                 /* stageIsStrips: in this slab column the rows of the strip are all present (consecutive columns) or
                  * all past their end */
                 const bool present = k < len[0];
-                const Pack<T, RPL> w = loadPackElementAligned<T, RPL>(x + (present ? s.c[u].v[0] - a.baseIndex : 0));
+                /* an absent strip still issues its load (no divergence in the stage): from the coefficient array, which
+                 * holds at least one whole strip whenever a stage runs -- x itself may be shorter than RPL elements */
+                const Pack<T, RPL> w = loadPackElementAligned<T, RPL>(present ? x + (s.c[u].v[0] - a.baseIndex) : a.cM);
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
                     use[u][t] = present;
                     xv[u][t] = w.v[t];
+                }
+            } else if constexpr (XTILE) {
+                /* from the tile where the column lies inside it (LDS reads retire on lgkmcnt: the stream prefetch,
+                 * on vmcnt, stays in flight); the branch over the global gathers is wavefront-uniform per slab
+                 * column and not taken when the tile covers the workgroup's columns */
+                bool outside = false;
+                unsigned at[RPL];
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    const int col = s.c[u].v[t] - a.baseIndex;
+                    use[u][t] = k < len[t] && col >= 0;
+                    at[t] = (unsigned)(col - tileBase);
+                    const bool inside = at[t] < tileCount;
+                    outside |= use[u][t] && !inside;
+                    xv[u][t] = tile[inside ? at[t] : 0u];
+                }
+                if (__ballot(outside) != 0ull) {
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t) {
+                        if (use[u][t] && at[t] >= tileCount)
+                            xv[u][t] = x[s.c[u].v[t] - a.baseIndex];
+                    }
                 }
             } else {
 #pragma unroll
@@ -271,6 +321,82 @@ __global__ __launch_bounds__(kBlockThreads) void slabSpmvKernel(const SlabArgs<T
     if constexpr (PIPE) {
         Stage cur, nxt;
         fetch(0, cur);
+        if constexpr (XTILE) {
+            /* Which slice of x?  Every row is sampled at its first and its last entry (the extremes of a row whose
+             * columns ascend; any row order is still correct, entries outside the tile are gathered from global
+             * memory).  The first index is in the stage just requested; the last costs one more load per row, in the
+             * same round trip.  If the span of the workgroup's rows fits the tile it starts at the lowest column,
+             * otherwise it is centred on the mean of the rows' middles (a few far-away rows then do not drag it off). */
+            int lastIndex[RPL];
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                lastIndex[t] = (phase == 0 && len[t] > 0) ? idxs[t + (long long)(len[t] - 1) * a.idxStride] : 0;
+            ColumnProbe mine{0x7fffffff, -0x7fffffff - 1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                if (phase == 0 && len[t] > 0) {
+                    const int first = cur.c[0].v[t] - a.baseIndex, last = lastIndex[t] - a.baseIndex;
+                    const int low = first < last ? first : last, high = first < last ? last : first;
+                    mine.lowest = low < mine.lowest ? low : mine.lowest;
+                    mine.highest = high > mine.highest ? high : mine.highest;
+                    mine.middles += ((long long)first + last) >> 1;
+                    mine.rows += 1;
+                }
+            }
+            mine.lowest = waveMin(mine.lowest);
+            mine.highest = waveMax(mine.highest);
+#pragma unroll
+            for (int m = 1; m < kWave; m <<= 1) {
+                mine.rows += laneXor(mine.rows, m);
+                const int lowHalf = laneXor((int)(unsigned)(mine.middles & 0xffffffffll), m);
+                const int highHalf = laneXor((int)(mine.middles >> 32), m);
+                mine.middles += ((long long)highHalf << 32) | (unsigned)lowHalf;
+            }
+            ColumnProbe* seen = ldsArray<ColumnProbe, WAVES>();
+            if (lane == 0)
+                seen[threadIdx.x >> 6] = mine;
+            __syncthreads();
+            ColumnProbe all{0x7fffffff, -0x7fffffff - 1, 0, 0};
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const ColumnProbe other = seen[w];
+                all.lowest = other.lowest < all.lowest ? other.lowest : all.lowest;
+                all.highest = other.highest > all.highest ? other.highest : all.highest;
+                all.rows += other.rows;
+                all.middles += other.middles;
+            }
+            if (all.rows > 0 && all.lowest >= 0) {
+                const long long span = (long long)all.highest - all.lowest + 1;
+                if (span <= TILE_ELEMS) {
+                    tileBase = all.lowest;
+                    tileCount = (unsigned)span;
+                } else {
+                    long long start = all.middles / all.rows - TILE_ELEMS / 2;
+                    start = start < all.lowest ? all.lowest : start;
+                    start = start + TILE_ELEMS > (long long)all.highest + 1 ? (long long)all.highest + 1 - TILE_ELEMS : start;
+                    tileBase = (int)start;
+                    tileCount = TILE_ELEMS;
+                }
+            }
+            /* coalesced copy: 16-byte pieces (global memory takes them at any element address), 4 per lane in flight */
+            constexpr int PIECE = 16 / (int)sizeof(T);
+            const T* __restrict__ from = x + tileBase;
+            const unsigned pieces = tileCount / PIECE;
+            for (unsigned p0 = threadIdx.x; p0 < pieces; p0 += 4u * BLOCK) {
+                Pack<T, PIECE> w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (p0 + q * BLOCK < pieces)
+                        w[q] = loadPackElementAligned<T, PIECE>(from + (size_t)(p0 + q * BLOCK) * PIECE);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (p0 + q * BLOCK < pieces)
+                        storePack<T, PIECE>(tile + (size_t)(p0 + q * BLOCK) * PIECE, w[q]);
+            }
+            if (pieces * PIECE + threadIdx.x < tileCount)
+                tile[pieces * PIECE + threadIdx.x] = from[pieces * PIECE + threadIdx.x];
+            __syncthreads();
+        }
         /* one stage: `form` says how its x values are fetched */
         auto stage = [&](auto form) {
             if constexpr (PIPE == 2) {
@@ -429,18 +555,52 @@ static bool alignedTo(const void* p, size_t bytes)
     return ((uintptr_t)p % bytes) == 0;
 }
 
-template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, int PIPE = 0, bool TAIL = false, int XPOLICY = 0, bool STRIPS = false>
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, int PIPE = 0, bool TAIL = false, int XPOLICY = 0, bool STRIPS = false,
+          int BLOCK = kBlockThreads, int TILE_BYTES = 0>
 static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
 {
     constexpr int GROUP_ROWS = (kWave / PH) * RPL;
+    constexpr int WAVES = BLOCK / kWave;
     const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
-    const unsigned blocks = (unsigned)((groups + kWavesPerBlock - 1) / kWavesPerBlock);
+    const unsigned blocks = (unsigned)((groups + WAVES - 1) / WAVES);
     if (nt)
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE, TAIL, XPOLICY, STRIPS>), dim3(blocks),
-                           dim3(kBlockThreads), 0, stream, a);
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, PIPE, TAIL, XPOLICY, STRIPS, BLOCK, TILE_BYTES>),
+                           dim3(blocks), dim3(BLOCK), 0, stream, a);
     else
-        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE, TAIL, XPOLICY, STRIPS>), dim3(blocks),
-                           dim3(kBlockThreads), 0, stream, a);
+        hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, false, UNROLL, PIPE, TAIL, XPOLICY, STRIPS, BLOCK, TILE_BYTES>),
+                           dim3(blocks), dim3(BLOCK), 0, stream, a);
+}
+
+/* The x-tile forms.  Workgroup size and tile size go together: the tile has to hold the columns of the workgroup's
+ * rows, and LDS (160 KiB per CU) divided by the tile is the number of workgroups a CU overlaps.  A lane walks whole
+ * rows (PH 1) with 4 slab columns per stage -- half the stage of the gather kernel: LDS gathers are short, and at 8 the
+ * kernel needs 148 VGPRs, which leaves room for one 512-lane workgroup per CU only.  Shape 0 is the default; the
+ * others exist for A/B runs (SPGPU_X_TILE_SHAPE):
+ *   1  one wavefront per 32-row group (PH = 2 * RPL, 2 columns per stage), 512 lanes, 64 KiB
+ *   2  1024 lanes, 128 KiB (one workgroup per CU)      3  256 lanes, 32 KiB
+ * The coefficient/index streams always carry the non-temporal hint here. */
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool TAIL, int BLOCK, int TILE_BYTES>
+static void launchTile(hipStream_t stream, const SlabArgs<T>& a)
+{
+    constexpr int GROUP_ROWS = (kWave / PH) * RPL;
+    constexpr int WAVES = BLOCK / kWave;
+    const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
+    const unsigned blocks = (unsigned)((groups + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, 2, TAIL, 0, false, BLOCK, TILE_BYTES>), dim3(blocks),
+                       dim3(BLOCK), 0, stream, a);
+}
+
+template <typename T, int RPL, bool IS_HELL>
+static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
+{
+    constexpr int PH1 = sizeof(T) == 16 ? 2 : 1; /* 16-byte elements keep the 2-phase shape of their default kernel */
+    constexpr bool TAIL = sizeof(T) != 16;
+    switch (shape) {
+    case 1: launchTile<T, RPL, (RPL > 1 ? 2 * RPL : 2), IS_HELL, (RPL > 1 ? 2 : 4), TAIL, 512, 65536>(stream, a); break;
+    case 2: launchTile<T, RPL, PH1, IS_HELL, 4, TAIL, 1024, 131072>(stream, a); break;
+    case 3: launchTile<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 32768>(stream, a); break;
+    default: launchTile<T, RPL, PH1, IS_HELL, 4, TAIL, 512, 65536>(stream, a); break;
+    }
 }
 
 template <typename T, bool IS_HELL>
@@ -487,11 +647,18 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
      * later call on the same matrix (same rP, same rows) reads that -- no synchronisation, whatever is there --
      * and takes the gather-only kernel when at least two of the three samples said gathers.  Both kernels are
      * correct for every matrix; a stale or missing answer only costs speed.  SPGPU_X_STRIPS = 0 / 1 fixes the form. */
+    /* How x is fetched (include/spgpu/tuning.h): the handle's hint, overridden by the environment knobs. */
+    int form = spgpuGetSpmvForm(handle);
+    if (tune->xStrips >= 0)
+        form = tune->xStrips ? SPGPU_SPMV_FORM_STRIPS : SPGPU_SPMV_FORM_GATHER;
+    if (tune->xTile >= 0)
+        form = tune->xTile ? SPGPU_SPMV_FORM_XTILE : (form == SPGPU_SPMV_FORM_XTILE ? SPGPU_SPMV_FORM_AUTO : form);
+    const bool tiled = form == SPGPU_SPMV_FORM_XTILE && (variant == 13 || variant == 21 || variant == 22);
     bool strips = false;
     a.feedback = nullptr;
-    if (!narrowVariant && WIDE > 1) {
-        if (tune->xStrips >= 0) {
-            strips = tune->xStrips != 0;
+    if (!narrowVariant && WIDE > 1 && !tiled) {
+        if (form != SPGPU_SPMV_FORM_AUTO) {
+            strips = form == SPGPU_SPMV_FORM_STRIPS;
         } else {
             int* seen = spgpuFormFeedback(handle, a.rP, a.rows);
             int gathers = 0;
@@ -524,14 +691,18 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
             case 17: launchSlab<T, WIDE, 1, IS_HELL, 8, 1, true>(stream, a, nt); break;
             case 22:
-                if (strips)
+                if (tiled)
+                    launchTiled<T, WIDE, IS_HELL>(stream, a, tune->xTileShape);
+                else if (strips)
                     launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true, 0, true>(stream, a, nt);
                 else
                     launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true>(stream, a, nt);
                 break;
             case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;
             default: /* 21 */
-                if (strips)
+                if (tiled)
+                    launchTiled<T, WIDE, IS_HELL>(stream, a, tune->xTileShape);
+                else if (strips)
                     launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true, 0, true>(stream, a, nt);
                 else
                     launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true>(stream, a, nt);
@@ -549,7 +720,12 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     case 15: launchSlab<T, 1, 2, IS_HELL, 8>(stream, a, nt); break;
     case 16: launchSlab<T, 1, 4, IS_HELL, 2, true>(stream, a, nt); break;
 #endif
-    default: launchSlab<T, 1, 2, IS_HELL, 4, 2>(stream, a, nt); break; /* 13 */
+    default: /* 13 */
+        if (tiled)
+            launchTiled<T, 1, IS_HELL>(stream, a, tune->xTileShape);
+        else
+            launchSlab<T, 1, 2, IS_HELL, 4, 2>(stream, a, nt);
+        break;
     }
 }
 

@@ -27,6 +27,7 @@
 #include "spgpu/device_scalars.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -244,6 +245,13 @@ template <int MODE, typename A> __device__ inline A blockCombine(A v, A* lds)
     return total;
 }
 
+/* What a reduction returns when the device could not deliver its partials. */
+template <typename A> static inline A notANumber();
+template <> inline float notANumber<float>() { return NAN; }
+template <> inline double notANumber<double>() { return NAN; }
+template <> inline cfloat notANumber<cfloat>() { return cfloat{NAN, NAN}; }
+template <> inline cdouble notANumber<cdouble>() { return cdouble{NAN, NAN}; }
+
 template <typename T, int MODE> struct AccOf { using type = typename RealOf<T>::type; };
 template <typename T> struct AccOf<T, kDot> { using type = T; };
 
@@ -354,8 +362,16 @@ static void reduceVectors(spgpuHandle_t handle, typename AccOf<T, MODE>::type* o
         else
             hipLaunchKernelGGL((reduceKernel<T, 1, MODE>), grid, dim3(kL1Threads), 0, s, dev, n, a0, b0,
                                (long long)pitch);
-        (void)hipMemcpyAsync(host, dev, sizeof(Acc) * (size_t)blocks * vectors, hipMemcpyDeviceToHost, s);
-        (void)hipStreamSynchronize(s);
+        hipError_t status = hipMemcpyAsync(host, dev, sizeof(Acc) * (size_t)blocks * vectors, hipMemcpyDeviceToHost, s);
+        if (status == hipSuccess)
+            status = hipStreamSynchronize(s);
+        if (status != hipSuccess) {
+            /* the pinned mirror holds whatever an earlier call left there: do not hand that out as a result */
+            for (int j = first; j < count; ++j)
+                out[j] = notANumber<Acc>();
+            fprintf(stderr, "spgpu: reduction failed: %s\n", hipGetErrorString(status));
+            return;
+        }
 
         for (int j = 0; j < vectors; ++j) {
             Acc total = zeroOf<Acc>();

@@ -1,6 +1,9 @@
 #pragma once
 /* Library-private declarations shared by the host C files and the HIP kernels. */
 #include "spgpu/core.h"
+#include "spgpu/tuning.h"
+
+#include <pthread.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -27,6 +30,8 @@ typedef struct SpgpuPrivateHandle {
     const void* formKey[8];
     int formRows[8];
     unsigned formNext;
+    pthread_mutex_t formLock; /* guards formKey / formRows / formNext */
+    int spmvForm;             /* SPGPU_SPMV_FORM_* set by spgpuSetSpmvForm (atomic) */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8
 #define SPGPU_FEEDBACK_SAMPLES 4
@@ -57,6 +62,8 @@ typedef struct SpgpuTuning {
     int spmmVariant; /* 0 */
     int l1Blocks;    /* 0: kernel default */
     int xStrips;     /* -1: by feedback */
+    int xTile;       /* -1: by the handle's hint */
+    int xTileShape;  /* 0 */
     int l1Nt;        /* -1: by size */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);

@@ -136,6 +136,60 @@ def ell_to_oell(ell):
     return out, r_idx[:n_rows]
 
 
+def oell_order(row_lengths, window=0, long_rows=0):
+    """The host order call (ell_conv.h oellOrder): returns (rIdx, sorted lengths)."""
+    rs = _i32(row_lengths)
+    n = int(rs.size)
+    r_idx, dst = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    capi.oellOrder(_p(r_idx), _p(dst), _p(rs if n else np.zeros(1, np.int32)), n, window, long_rows)
+    return r_idx[:n], dst[:n]
+
+
+def coo_to_ordered_hell_device(handle, n_rows, coo_rows, coo_cols, coo_vals, letter, hack_size=32, window=0, long_rows=0,
+                               coo_base=0, hell_base=0, order=True):
+    """COO arrays in HBM (torch tensors) -> HELL in HBM with its rows ordered by length, all through the C ABI:
+    spgpuCooRowLengthsDevice -> spgpuOellOrderDevice -> spgpuCooPermuteRowsDevice -> spgpuCooRowLengthsDevice ->
+    spgpuHellPlanDevice -> spgpuCooToHellDevice.  order=False skips the ordering (plain HELL, rIdx None).
+    Returns a dict of torch tensors (cM, rP, hack_offsets, rS, rIdx) plus sizes."""
+    import torch
+    dev = coo_rows.device
+    nnz = int(coo_rows.numel())
+    torch.cuda.synchronize()   # the COO arrays were filled on torch's stream; the library works on the handle's
+    work = torch.empty(capi.spgpuCooConvertWorkBytes(n_rows, nnz), dtype=torch.uint8, device=dev)
+    lengths = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
+    longest = C.c_int(0)
+    ok = lambda status: status == capi.SPGPU_SUCCESS or (_ for _ in ()).throw(RuntimeError(f"status {status}"))
+    ok(capi.spgpuCooRowLengthsDevice(handle, _dp(lengths), C.byref(longest), n_rows, nnz, _dp(coo_rows), coo_base, _dp(work)))
+    r_idx = None
+    rows_in = coo_rows
+    if order:
+        order_work = torch.empty(capi.spgpuOellOrderWorkBytes(n_rows), dtype=torch.uint8, device=dev)
+        r_idx = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
+        sorted_lengths = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
+        ok(capi.spgpuOellOrderDevice(handle, _dp(r_idx), _dp(sorted_lengths), _dp(lengths), n_rows, window, long_rows,
+                                     _dp(order_work)))
+        inverse = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
+        rows_in = torch.empty_like(coo_rows)
+        ok(capi.spgpuCooPermuteRowsDevice(handle, _dp(rows_in), _dp(coo_rows), nnz, _dp(r_idx), n_rows, coo_base, _dp(inverse)))
+        # returns a host scalar, i.e. synchronises the stream: the order scratch can go afterwards
+        ok(capi.spgpuCooRowLengthsDevice(handle, _dp(lengths), C.byref(longest), n_rows, nnz, _dp(rows_in), coo_base, _dp(work)))
+        del order_work, inverse
+    hacks = (n_rows + hack_size - 1) // hack_size
+    hack_offsets = torch.empty(max(hacks, 1), dtype=torch.int32, device=dev)
+    height = C.c_int(0)
+    ok(capi.spgpuHellPlanDevice(handle, C.byref(height), _dp(hack_offsets), hack_size, n_rows, _dp(lengths), _dp(work)))
+    slots = hack_size * height.value
+    cM = torch.zeros(max(slots, 1), dtype=coo_vals.dtype, device=dev)
+    rP = torch.zeros(max(slots, 1), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ok(capi.spgpuCooToHellDevice(handle, _dp(cM), _dp(rP), _dp(hack_offsets), hack_size, hell_base, n_rows, nnz,
+                                 _dp(rows_in), _dp(coo_cols), _dp(coo_vals), coo_base, capi.TYPE_CODE[letter], _dp(lengths),
+                                 _dp(work)))
+    torch.cuda.synchronize()
+    return dict(letter=letter, rows=n_rows, hack_size=hack_size, nnz=nnz, slots=slots, cM=cM, rP=rP, hack_offsets=hack_offsets,
+                rS=lengths, rIdx=r_idx, base=hell_base, longest=longest.value)
+
+
 # ---- device residency + SpMV calls -------------------------------------------------
 
 def to_device(a, device="cuda:0"):

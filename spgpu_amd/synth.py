@@ -156,6 +156,12 @@ def hell_uniform_on_device(n_rows, nnz_per_row, pattern="random", letter="D", ha
     elif pattern == "random":
         cols = torch.randint(0, n_cols, (hacks, L, hs), device=device, generator=gen, dtype=torch.int64)
         cols = torch.sort(cols, dim=1).values
+    elif pattern.startswith("near"):
+        # like "window" with a narrow window: columns random inside +-W of the row (pattern "near2048": W = 2048)
+        w = min(2 * int(pattern[4:] or 2048), n_cols)
+        cols = (row + torch.randint(-(w // 2), w // 2, (hacks, L, hs), device=device, generator=gen,
+                                    dtype=torch.int64)) % n_cols
+        cols = torch.sort(cols, dim=1).values
     elif pattern == "window":
         w = min(65536, n_cols)
         cols = (row + torch.randint(-(w // 2), w // 2, (hacks, L, hs), device=device, generator=gen,
@@ -324,3 +330,52 @@ def ragged_rows_to_host(h, first_row, n_rows):
     return dict(letter=h["letter"], rows=n_rows, values=h["cM"][s0:s1].cpu().numpy(), indices=h["rP"][s0:s1].cpu().numpy(),
                 hack_offsets=(ho[h0:h1] - s0).astype(np.int32), hack_size=hs,
                 row_lengths=h["rS"][first_row:first_row + n_rows].cpu().numpy(), base=0)
+
+
+def ragged_coo_on_device(lengths, n_cols, pattern="near", near=2048, letter="D", seed=5, device="cuda:0"):
+    """COO triplets in HBM, row-major, of a matrix with the given row lengths (the north_star target: power-law
+    lengths, mean 32, max 2048).  A row's columns ascend and are distinct (stratified draw: the k-th of L entries lies
+    in the k-th of L equal pieces of the row's column range):
+
+    pattern "near":   the range is [row - near, row + near), wrapped into [0, n_cols) -- the locality of a mesh or a
+                      banded problem, without consecutive columns
+    pattern "random": the range is all of [0, n_cols)
+
+    Returns (rows int32, cols int32, vals) torch tensors; nnz = sum(lengths)."""
+    import torch
+    L = torch.as_tensor(np.asarray(lengths), dtype=torch.int64, device=device)
+    n_rows = int(L.numel())
+    start = torch.cumsum(L, 0) - L
+    nnz = int(L.sum().item())
+    row = torch.repeat_interleave(torch.arange(n_rows, device=device, dtype=torch.int64), L, output_size=nnz)
+    k = torch.arange(nnz, device=device, dtype=torch.int64) - start[row]
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    u = torch.rand(nnz, device=device, generator=gen, dtype=torch.float64)
+    length = L[row]
+    if pattern == "near":
+        width = 2 * near
+        assert int(L.max().item()) <= width
+        cols = (row - near + ((k.to(torch.float64) + u) * width / length.to(torch.float64)).to(torch.int64)) % n_cols
+    elif pattern == "random":
+        cols = torch.clamp(((k.to(torch.float64) + u) * n_cols / length.to(torch.float64)).to(torch.int64), max=n_cols - 1)
+    else:
+        raise ValueError(pattern)
+    del u, k, length, start
+    rdt = {"S": torch.float32, "D": torch.float64}[letter]
+    vals = torch.rand(nnz, device=device, generator=gen, dtype=rdt)
+    return row.to(torch.int32), cols.to(torch.int32), vals
+
+
+def hell_rows_to_host_general(h, first_row, n_rows):
+    """Rows [first_row, first_row + n_rows) (hack-aligned) of ANY device HELL dict (cM, rP, hack_offsets, rS, hack_size,
+    slots) as a host HELL dict with rebased hackOffsets."""
+    hs = h["hack_size"]
+    assert first_row % hs == 0 and n_rows % hs == 0
+    h0, h1 = first_row // hs, (first_row + n_rows) // hs
+    ho = h["hack_offsets"].cpu().numpy().astype(np.int64)
+    s0 = int(ho[h0])
+    s1 = int(ho[h1]) if h1 < ho.size else int(h["slots"])
+    return dict(letter=h["letter"], rows=n_rows, values=h["cM"][s0:s1].cpu().numpy(), indices=h["rP"][s0:s1].cpu().numpy(),
+                hack_offsets=(ho[h0:h1] - s0).astype(np.int32), hack_size=hs,
+                row_lengths=h["rS"][first_row:first_row + n_rows].cpu().numpy(), base=h.get("base", 0))

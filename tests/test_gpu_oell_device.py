@@ -1,0 +1,221 @@
+"""GPU: rows ordered by length in HBM (include/spgpu/oell_device.h) and the x-tile form of the ELL/HELL SpMV that the
+ordered matrices are run with (spgpuSetSpmvForm, include/spgpu/tuning.h).
+
+Order: byte-identical to the host oellOrder, which for one window is the reference's ellToOell order
+(tests/test_oell_order.py pins that against the reference's own object).  SpMV: every form against the oracle in
+the kernel's summation order, bit for bit, and against the extended-precision fixtures within the north_star bound."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _dp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _device_order(gpu, lengths, window, long_rows):
+    import torch
+    from spgpu_amd import capi
+    n = int(lengths.size)
+    rs = torch.from_numpy(np.ascontiguousarray(lengths, np.int32)).cuda() if n else torch.zeros(1, dtype=torch.int32, device="cuda")
+    work = torch.empty(max(capi.spgpuOellOrderWorkBytes(n), 256), dtype=torch.uint8, device="cuda")
+    r_idx = torch.full((max(n, 1),), -7, dtype=torch.int32, device="cuda")
+    dst = torch.full((max(n, 1),), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert capi.spgpuOellOrderDevice(gpu, _dp(r_idx), _dp(dst), _dp(rs), n, window, long_rows, _dp(work)) == capi.SPGPU_SUCCESS
+    torch.cuda.synchronize()
+    return r_idx[:n].cpu().numpy(), dst[:n].cpu().numpy()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 33, 1000, 70001])
+@pytest.mark.parametrize("window,long_rows", [(0, 0), (32, 0), (4096, 0), (0, 6), (512, 6), (100000, 0)])
+def test_order_equals_host_order(gpu, n, window, long_rows):
+    from spgpu_amd import formats
+    rng = np.random.default_rng(n + 17 * window + long_rows)
+    lengths = np.minimum(rng.zipf(1.6, size=n), 60).astype(np.int32)
+    want_idx, want_len = formats.oell_order(lengths, window, long_rows)
+    got_idx, got_len = _device_order(gpu, lengths, window, long_rows)
+    assert got_idx.tobytes() == want_idx.tobytes()
+    assert got_len.tobytes() == want_len.tobytes()
+
+
+@pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
+@pytest.mark.parametrize("window,long_rows", [(0, 0), (64, 8)])
+def test_ell_to_oell_device_equals_host(gpu, letter, window, long_rows):
+    """spgpuEllToOellDevice against the host ellToOell (window 0: the reference's call) / the host order + copy."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 777
+    lengths = np.minimum(np.random.default_rng(3).zipf(1.5, size=n), 30)
+    _, _, r, c, v = synth.random_rows_coo(n, 900, lengths, seed=4, letter=letter)
+    ell = formats.coo_to_ell(n, r, c, v)
+    if (window, long_rows) == (0, 0):
+        want, want_idx = formats.ell_to_oell(ell)
+    else:
+        want_idx, want_len = formats.oell_order(ell["row_lengths"], window, long_rows)
+        vals, idx = np.zeros_like(ell["values"]), np.zeros_like(ell["indices"])
+        for i, src in enumerate(want_idx):
+            for k in range(ell["row_lengths"][src]):
+                vals[i + k * ell["pitch"]] = ell["values"][src + k * ell["pitch"]]
+                idx[i + k * ell["pitch"]] = ell["indices"][src + k * ell["pitch"]]
+        want = dict(ell, values=vals, indices=idx, row_lengths=want_len)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    sv, si, rs = d(ell["values"]), d(ell["indices"]), d(ell["row_lengths"])
+    dv, di = torch.zeros_like(sv), torch.zeros_like(si)
+    r_idx, dst_rs = torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda")
+    work = torch.empty(capi.spgpuOellOrderWorkBytes(n), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    assert capi.spgpuEllToOellDevice(gpu, _dp(r_idx), _dp(dv), _dp(di), _dp(dst_rs), _dp(sv), _dp(si), _dp(rs), ell["pitch"],
+                                     ell["pitch"], n, capi.TYPE_CODE[letter], window, long_rows, _dp(work)) == capi.SPGPU_SUCCESS
+    torch.cuda.synchronize()
+    assert r_idx.cpu().numpy().tobytes() == np.ascontiguousarray(want_idx, np.int32).tobytes()
+    assert dst_rs.cpu().numpy().tobytes() == np.ascontiguousarray(want["row_lengths"], np.int32).tobytes()
+    assert dv.cpu().numpy().tobytes() == want["values"].tobytes()
+    assert di.cpu().numpy().tobytes() == want["indices"].tobytes()
+
+
+def _ordered_case(gpu, n, letter, window, long_rows, pattern="near", near=300, hack=32, base=0):
+    """A ragged matrix through the whole device route; returns (device HELL dict, host COO, host HELL built on the host
+    from the permuted COO)."""
+    import torch
+    from spgpu_amd import formats, synth
+    lengths = np.minimum(synth.power_law_lengths(n, 12.0, 400, 9), 2 * near)
+    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, near, letter, seed=7)
+    if base:
+        rows_t, cols_t = rows_t + base, cols_t + base
+    h = formats.coo_to_ordered_hell_device(gpu, n, rows_t, cols_t, vals_t, letter, hack, window, long_rows, coo_base=base,
+                                           hell_base=base)
+    return h, (rows_t.cpu().numpy(), cols_t.cpu().numpy(), vals_t.cpu().numpy()), lengths
+
+
+@pytest.mark.parametrize("window,long_rows", [(0, 0), (256, 0), (512, 40)])
+@pytest.mark.parametrize("base", [0, 1])
+def test_coo_route_builds_the_ordered_hell(gpu, window, long_rows, base):
+    """Order + permuted COO rows + spgpuCooToHellDevice == the host converters on the host-permuted COO, byte for byte;
+    row i of the result is row rIdx[i] of the original."""
+    from spgpu_amd import formats
+    n = 5000
+    h, (r, c, v), lengths = _ordered_case(gpu, n, "D", window, long_rows, base=base)
+    want_idx, want_len = formats.oell_order(lengths, window, long_rows)
+    assert h["rIdx"].cpu().numpy().tobytes() == want_idx.tobytes()
+    inverse = np.empty(n, np.int64)
+    inverse[want_idx] = np.arange(n)
+    hell = formats.ell_to_hell(formats.coo_to_ell(n, inverse[r - base] + base, c, v, coo_base=base, ell_base=base), 32)
+    assert h["rS"][:n].cpu().numpy().tobytes() == want_len.tobytes() == hell["row_lengths"].tobytes()
+    assert h["hack_offsets"].cpu().numpy().tobytes() == hell["hack_offsets"].tobytes()
+    assert h["cM"][:h["slots"]].cpu().numpy().tobytes() == hell["values"].tobytes()
+    assert h["rP"][:h["slots"]].cpu().numpy().tobytes() == hell["indices"].tobytes()
+
+
+# the x-tile kernels' summation orders (csrc/ellpack_spmv.hip launchTiled), as oracle_api.spmv_tail parameters
+def tile_shape(letter, shape):
+    rpl = {"S": 4, "D": 2, "C": 2, "Z": 1}[letter]
+    if letter == "Z":
+        return None  # two phases, no tail: plain 2-phase order
+    if shape == 1:
+        return dict(group_rows=32, rows_per_lane=rpl, step=2 * rpl * 2, tail_lanes=16, phases=2 * rpl)
+    return dict(group_rows=64 * rpl, rows_per_lane=rpl, step=4, tail_lanes=16, phases=1)
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2, 3])
+@pytest.mark.parametrize("letter", ["S", "D"])
+@pytest.mark.parametrize("window,long_rows,pattern", [(512, 40, "near"), (0, 0, "near"), (1024, 0, "random")])
+def test_tile_form_through_ridx_bit_exact(gpu, tuning, letter, shape, window, long_rows, pattern):
+    """Ordered ragged matrix + rIdx, x-tile form: equals the oracle in the kernel's order bit for bit (columns inside the
+    tile come from LDS, the others from global memory -- "random" and the global sort exercise the mix), beta != 0 and
+    in-place included; and equals the SAME product computed from the unordered matrix within the north_star bound."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    tuning(SPGPU_X_TILE_SHAPE=shape)
+    n = 6000 + 13
+    h, (r, c, v), lengths = _ordered_case(gpu, n, letter, window, long_rows, pattern=pattern)
+    sub = dict(letter=letter, rows=n, values=h["cM"][:h["slots"]].cpu().numpy(), indices=h["rP"][:h["slots"]].cpu().numpy(),
+               hack_offsets=h["hack_offsets"].cpu().numpy(), hack_size=32, row_lengths=h["rS"][:n].cpu().numpy(), base=0)
+    r_idx = h["rIdx"].cpu().numpy()
+    x = synth.values_for(letter, 11, n)
+    y = synth.values_for(letter, 12, n)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_XTILE)
+    try:
+        for alpha, beta, in_place in ((1.0, 0.0, False), (-0.75, 0.5, False), (2.0, 1.0, True)):
+            dz = dy.clone() if in_place else torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            capi.hellspmv[letter](gpu, _dp(dz), _dp(dz if in_place else (dy if beta != 0 else None)), capi.scalar(letter, alpha),
+                                  _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), _dp(h["rIdx"]), 12, n,
+                                  _dp(dx), capi.scalar(letter, beta), 0)
+            torch.cuda.synchronize()
+            got = dz.cpu().numpy()
+            want = O.spmv_tail(sub, x, y if beta != 0 else None, alpha, beta, r_idx=r_idx, **tile_shape(letter, shape))
+            assert got.tobytes() == want.tobytes(), (alpha, beta, in_place)
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    # independent of any summation order: alpha*A*x from the ORIGINAL triplets in extended precision
+    exact = np.zeros(n, np.longdouble)
+    scale = np.zeros(n, np.longdouble)
+    np.add.at(exact, r, v.astype(np.longdouble) * x[c].astype(np.longdouble))
+    np.add.at(scale, r, np.abs(v.astype(np.longdouble) * x[c].astype(np.longdouble)))
+    dz = torch.empty(n, dtype=dx.dtype, device="cuda")
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_XTILE)
+    try:
+        capi.hellspmv[letter](gpu, _dp(dz), None, capi.scalar(letter, 1.0), _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]),
+                              _dp(h["rS"]), _dp(h["rIdx"]), 12, n, _dp(dx), capi.scalar(letter, 0.0), 0)
+        torch.cuda.synchronize()
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    tol = {"S": 1e-4, "D": 1e-6}[letter]
+    assert np.all(np.abs(dz.cpu().numpy().astype(np.longdouble) - exact) <= tol * scale + np.finfo(np.float64).tiny)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
+                                        if os.path.basename(p)[:-4] not in ("empty_d", "onerow_z")))
+@pytest.mark.parametrize("form", ["gather", "strips", "xtile"])
+def test_every_form_on_the_fixtures(gpu, name, form):
+    """The hint changes how x is fetched, never the sums: all four types, both formats, against the fixtures'
+    extended-precision vectors, and gather == strips bit for bit (same kernel shape)."""
+    import torch
+    from spgpu_amd import capi, formats
+    from test_gpu_spmv import _load, _mats, _run, _within
+    g = _load(name)
+    letter, ell, hell, _ = _mats(g)
+    alpha, beta = g["alpha"][()], g["beta"][()]
+    y = g["y"] if beta != 0 else None
+    capi.spgpuSetSpmvForm(gpu, {"gather": capi.FORM_GATHER, "strips": capi.FORM_STRIPS, "xtile": capi.FORM_XTILE}[form])
+    try:
+        assert capi.spgpuGetSpmvForm(gpu) != capi.FORM_AUTO
+        for mat in (formats.DeviceHell(hell), formats.DeviceEll(ell), formats.DeviceEll(ell, with_row_sizes=False)):
+            z = _run(gpu, mat, g["x"], y, alpha, beta)
+            assert _within(z, g, letter) <= 1.0
+            if form != "xtile" and not (isinstance(mat, formats.DeviceEll) and mat.rS is None):
+                assert z.tobytes() == O.default_spmv(hell if isinstance(mat, formats.DeviceHell) else ell, g["x"], y, alpha, beta).tobytes()
+            elif form == "xtile" and letter != "Z" and not (isinstance(mat, formats.DeviceEll) and mat.rS is None):
+                want = O.spmv_tail(hell if isinstance(mat, formats.DeviceHell) else ell, g["x"], y, alpha, beta, **tile_shape(letter, 0))
+                assert z.tobytes() == want.tobytes()
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+
+
+def test_one_column_matrix_strips_form(gpu):
+    """x shorter than a strip (1 column): the strip-capable kernel must not read past it (an absent strip loads from the
+    coefficient array instead).  Result checked; the out-of-bounds read itself would need a sanitizer to see."""
+    import torch
+    from spgpu_amd import capi, formats
+    n = 300
+    r = np.arange(n, dtype=np.int32)
+    c = np.zeros(n, np.int32)
+    v = np.linspace(1.0, 2.0, n)
+    hell = formats.ell_to_hell(formats.coo_to_ell(n, r, c, v), 32)
+    x = np.array([3.0])
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_STRIPS)
+    try:
+        from test_gpu_spmv import _run
+        z = _run(gpu, formats.DeviceHell(hell), x, None, 1.0, 0.0)
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    assert z.tobytes() == (v * 3.0).tobytes()
