@@ -634,16 +634,34 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
  * finally the `phases` partials combined pairwise.
  * Same arithmetic and epilogue as orc_?hellspmv / orc_?ellspmv; hackOffsets == NULL selects ELL addressing. */
 #define ORC_DEFINE_TAIL(P, T)                                                                                 \
-    void orc_##P##spmv_tail(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
+    /* length of row i as the slab kernel walks it: with the deep split (deepCap > 0) the rows of a 32-row */   \
+    /* sub-group whose longest row exceeds deepCap stop at deepCap there */                                    \
+    /* depth of row i's 32-row sub-group if the sub-group is deep, else 0 */                                  \
+    static int P##_deep_group(const int* rS, int maxNnz, int rows, int i, int deepCap)                        \
+    {                                                                                                         \
+        if (deepCap <= 0) return 0;                                                                           \
+        const int s0 = i / 32 * 32;                                                                           \
+        int depth = 0;                                                                                        \
+        for (int r = s0; r < s0 + 32 && r < rows; ++r)                                                        \
+            if ((rS ? rS[r] : maxNnz) > depth) depth = rS ? rS[r] : maxNnz;                                   \
+        return depth > deepCap ? depth : 0;                                                                   \
+    }                                                                                                         \
+    static int P##_walked(const int* rS, int maxNnz, int rows, int i, int deepCap)                            \
+    {                                                                                                         \
+        const int l = rS ? rS[i] : maxNnz;                                                                    \
+        return (P##_deep_group(rS, maxNnz, rows, i, deepCap) && l > deepCap) ? deepCap : l;                   \
+    }                                                                                                         \
+    void orc_##P##spmv_deep(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
                             const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \
                             const int* rIdx, int rows, const T* x, T beta, int baseIndex, int groupRows,      \
-                            int rowsPerLane, int step, int tailLanes, int phases)                             \
+                            int rowsPerLane, int step, int tailLanes, int phases, int deepCap, int deepPhases,\
+                            int deepChunk)                                                                    \
     {                                                                                                         \
         for (int g0 = 0; g0 < rows; g0 += groupRows) {                                                        \
             const int gEnd = g0 + groupRows < rows ? g0 + groupRows : rows;                                   \
             int longest = 0;                                                                                  \
             for (int i = g0; i < gEnd; ++i) {                                                                 \
-                const int l = rS ? rS[i] : maxNnz;                                                            \
+                const int l = P##_walked(rS, maxNnz, rows, i, deepCap);                                       \
                 if (l > longest) longest = l;                                                                 \
             }                                                                                                 \
             int tailFrom = longest;                                                                           \
@@ -652,7 +670,7 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                 for (int s0 = g0; s0 < gEnd; s0 += rowsPerLane) {                                             \
                     int laneLongest = 0;                                                                      \
                     for (int i = s0; i < s0 + rowsPerLane && i < gEnd; ++i) {                                 \
-                        const int l = rS ? rS[i] : maxNnz;                                                    \
+                        const int l = P##_walked(rS, maxNnz, rows, i, deepCap);                               \
                         if (l > laneLongest) laneLongest = l;                                                 \
                     }                                                                                         \
                     busy += kBase < laneLongest;                                                              \
@@ -660,7 +678,8 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                 if (busy * phases <= tailLanes) { tailFrom = kBase; break; } /* every strip has `phases` lanes */ \
             }                                                                                                 \
             for (int i = g0; i < gEnd; ++i) {                                                                 \
-                const int len = rS ? rS[i] : maxNnz;                                                          \
+                const int fullLen = rS ? rS[i] : maxNnz;                                                      \
+                const int len = P##_walked(rS, maxNnz, rows, i, deepCap);                                     \
                 const size_t slot0 = hackOffsets ? (size_t)hackOffsets[i / hackSize] + (size_t)(i % hackSize) : (size_t)i; \
                 const size_t vs = hackOffsets ? (size_t)hackSize : (size_t)cMPitch;                           \
                 const size_t is = hackOffsets ? (size_t)hackSize : (size_t)rPPitch;                           \
@@ -680,9 +699,35 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                     }                                                                                         \
                     head[0] = P##_add(head[0], P##_combine(part, 64));                                        \
                 }                                                                                             \
-                P##_store(z, y, rIdx ? rIdx[i] : i, alpha, P##_combine(head, phases), beta);                  \
+                T total = P##_combine(head, phases);                                                          \
+                const int subDepth = P##_deep_group(rS, maxNnz, rows, i, deepCap);                            \
+                if (subDepth) {                                                                               \
+                    /* deepSpmvKernel: columns >= deepCap in chunks of deepChunk; a chunk's deepPhases phase sums */ \
+                    /* (each over ascending k) are combined pairwise; the chunk sums join the slab kernel's sum in */ \
+                    /* chunk order */                                                                         \
+                    /* chunk order; a row shorter than its sub-group adds the later chunks' +0 as the kernel does */ \
+                    for (int c0 = deepCap; c0 < subDepth; c0 += deepChunk) {                                  \
+                        T part[ORC_MAX_PHASES];                                                               \
+                        for (int p = 0; p < deepPhases; ++p) part[p] = P##_zero();                            \
+                        for (int k = c0; k < fullLen && k < c0 + deepChunk; ++k) {                            \
+                            const int col = rP[slot0 + (size_t)k * is] - baseIndex;                           \
+                            if (col >= 0)                                                                     \
+                                part[(k - deepCap) % deepPhases] = P##_fma(cM[slot0 + (size_t)k * vs], x[col], part[(k - deepCap) % deepPhases]); \
+                        }                                                                                     \
+                        total = P##_add(total, P##_combine(part, deepPhases));                                \
+                    }                                                                                         \
+                }                                                                                             \
+                P##_store(z, y, rIdx ? rIdx[i] : i, alpha, total, beta);                                      \
             }                                                                                                 \
         }                                                                                                     \
+    }                                                                                                         \
+    void orc_##P##spmv_tail(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
+                            const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \
+                            const int* rIdx, int rows, const T* x, T beta, int baseIndex, int groupRows,      \
+                            int rowsPerLane, int step, int tailLanes, int phases)                             \
+    {                                                                                                         \
+        orc_##P##spmv_deep(z, y, alpha, cM, rP, hackSize, hackOffsets, cMPitch, rPPitch, rS, maxNnz, rIdx, rows, x, beta, \
+                           baseIndex, groupRows, rowsPerLane, step, tailLanes, phases, 0, 1, 1);              \
     }
 ORC_DEFINE_TAIL(s, float)
 ORC_DEFINE_TAIL(d, double)

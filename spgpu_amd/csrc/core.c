@@ -86,6 +86,8 @@ void spgpuDestroy(spgpuHandle_t pHandle)
      * for defaultStream, before freeing them.  A graph captured from this handle must not be replayed after this. */
     hipDeviceSynchronize();
     hipFree(h->reduceScratch);
+    if (h->deepScratch)
+        hipFree(h->deepScratch);
     hipHostFree(h->reduceHost);
     hipHostFree(h->formFeedback);
     hipStreamDestroy(h->pub.defaultStream);
@@ -155,6 +157,38 @@ int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows)
     return slot;
 }
 
+/* ---- deep queues of the ELL/HELL SpMV (spgpu_internal.h) ---- */
+spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, int** counts, SpgpuDeepEntry** entries, void** partials)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    const size_t slots = (size_t)SPGPU_DEEP_QUEUES * SPGPU_DEEP_QUEUE_ENTRIES;
+    const size_t countBytes = (size_t)SPGPU_DEEP_QUEUES * sizeof(int);
+    pthread_mutex_lock(&h->formLock);
+    if (!h->deepScratch) {
+        /* first use: one allocation and one blocking memset (not capturable in a graph: warm the handle up first) */
+        const size_t bytes = countBytes + slots * (sizeof(SpgpuDeepEntry) + 32 * 16);
+        int previous = 0;
+        hipGetDevice(&previous);
+        hipSetDevice(h->pub.device);
+        void* p = NULL;
+        if (hipMalloc(&p, bytes) == hipSuccess) {
+            if (hipMemset(p, 0, countBytes) == hipSuccess)
+                h->deepScratch = p;
+            else
+                hipFree(p);
+        }
+        hipSetDevice(previous);
+    }
+    char* base = (char*)h->deepScratch;
+    pthread_mutex_unlock(&h->formLock);
+    if (!base)
+        return SPGPU_OUTOFMEMORY;
+    *counts = (int*)base;
+    *entries = (SpgpuDeepEntry*)(base + countBytes);
+    *partials = base + countBytes + slots * sizeof(SpgpuDeepEntry);
+    return SPGPU_SUCCESS;
+}
+
 /* ---- per-handle kernel-form hint (include/spgpu/tuning.h) ---- */
 void spgpuSetSpmvForm(spgpuHandle_t pHandle, int form)
 {
@@ -193,6 +227,10 @@ void spgpuTuningReload(void)
     t.xStrips = envInt("SPGPU_X_STRIPS", -1);
     t.xTile = envInt("SPGPU_X_TILE", -1);
     t.xTileShape = envInt("SPGPU_X_TILE_SHAPE", 0);
+    t.deepSplit = envInt("SPGPU_DEEP_SPLIT", -1);
+    t.deepCap = envInt("SPGPU_DEEP_CAP", 128);
+    t.ragged = envInt("SPGPU_RAGGED", 1);
+    t.raggedShape = envInt("SPGPU_RAGGED_SHAPE", 0);
     t.l1Nt = envInt("SPGPU_L1_NT", -1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);

@@ -71,6 +71,11 @@ template <typename T> struct SlabArgs {
     int wideIO;   /* y and z are aligned for RPL-wide access */
     int tailLanes; /* TAIL kernels: switch to whole-wave rows when <= this many lanes are busy */
     int* feedback; /* STRIPS kernels: pinned host ints the sample wavefronts report their form to, or NULL */
+    /* DEEP kernels: 32-row sub-groups deeper than deepCap hand their columns >= deepCap to deepSpmvKernel */
+    int deepCap;
+    int* deepCounts;             /* [SPGPU_DEEP_QUEUES] entries registered per queue (may exceed the queue's capacity) */
+    SpgpuDeepEntry* deepEntries; /* [SPGPU_DEEP_QUEUES][SPGPU_DEEP_QUEUE_ENTRIES] */
+    T* deepPartials;             /* [..][..][32] row sums over the columns < deepCap */
 };
 
 constexpr int kBlockThreads = 256;
@@ -131,7 +136,7 @@ __device__ inline long long sampleGroup(long long groups, int q)
  *        counts, so a placement / allocation effect), and the host picks per matrix (launchSlabFamily).
  */
 template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PIPE, bool TAIL, int XPOLICY = 0, bool STRIPS = false,
-          int BLOCK = kBlockThreads, int TILE_BYTES = 0>
+          int BLOCK = kBlockThreads, int TILE_BYTES = 0, bool DEEP = false, int GPW = 1>
 __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
@@ -141,16 +146,127 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
     constexpr int TILE_ELEMS = TILE_BYTES / (int)sizeof(T);
 
     const int lane = threadIdx.x & (kWave - 1);
-    const long long group = (long long)blockIdx.x * WAVES + (threadIdx.x >> 6);
-    const long long groupRow0 = group * GROUP_ROWS;
-    if constexpr (!XTILE) {
-        if (groupRow0 >= a.rows)
-            return; /* whole wavefront leaves together */
-    }
-    /* XTILE: a wavefront past the last row stays for the workgroup's barriers; all its rows have length 0 */
-
     const int sub = lane % LPC;   /* which RPL-row strip of the group */
     const int phase = lane / LPC; /* which residue class of k */
+    const T* __restrict__ x = a.x;
+
+    /* GPW groups per wavefront (x-tile forms: 2).  A workgroup owns GPW * WAVES consecutive groups and wavefront w takes
+     * the groups w and 2 * WAVES - 1 - w: when the rows were ordered by length the depths along a workgroup's groups
+     * rise or fall monotonically, and pairing the two ends gives every wavefront about the same work -- the tile stays
+     * allocated until the slowest wavefront is done.  It also halves the tile fills per row. */
+    static_assert(GPW == 1 || GPW == 2, "one group per wavefront, or the two ends of the workgroup's range");
+    auto groupOfTurn = [&](int turn) -> long long {
+        const int wave = threadIdx.x >> 6;
+        return (long long)blockIdx.x * (WAVES * GPW) + (turn == 0 ? wave : 2 * WAVES - 1 - wave);
+    };
+
+    /* XTILE: x[tileBase .. tileBase + tileCount) lives in `tile` once the prologue below has run */
+    T* tile = nullptr;
+    int tileBase = 0;
+    unsigned tileCount = 0;
+    if constexpr (XTILE) {
+        tile = ldsArray<T, TILE_ELEMS>();
+        /* Which slice of x?  Every row of the workgroup is sampled at its first and its last entry (the extremes of a
+         * row whose columns ascend; any row order is still correct, entries outside the tile are gathered from global
+         * memory).  If the span of the workgroup's rows fits the tile it starts at the lowest column, otherwise it is
+         * centred on the mean of the rows' middles (a few far-away rows then do not drag it off). */
+        ColumnProbe mine{0x7fffffff, -0x7fffffff - 1, 0, 0};
+        if (phase == 0) {
+            int first[GPW][RPL], last[GPW][RPL], lenAt[GPW][RPL];
+#pragma unroll
+            for (int turn = 0; turn < GPW; ++turn) {
+                const long long r0 = groupOfTurn(turn) * GROUP_ROWS + (long long)sub * RPL;
+                long long at = 0;
+                if (r0 < a.rows) {
+                    if constexpr (IS_HELL) {
+                        const unsigned u0 = (unsigned)r0, hs = (unsigned)a.hackSize;
+                        at = (long long)a.hackOffsets[u0 / hs] + (u0 % hs);
+                    } else {
+                        at = r0;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    const long long r = r0 + t;
+                    lenAt[turn][t] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+                    first[turn][t] = lenAt[turn][t] > 0 ? a.rP[at + t] : 0;
+                    last[turn][t] = lenAt[turn][t] > 0 ? a.rP[at + t + (long long)(lenAt[turn][t] - 1) * a.idxStride] : 0;
+                }
+            }
+#pragma unroll
+            for (int turn = 0; turn < GPW; ++turn) {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    if (lenAt[turn][t] > 0) {
+                        const int f = first[turn][t] - a.baseIndex, l = last[turn][t] - a.baseIndex;
+                        const int low = f < l ? f : l, high = f < l ? l : f;
+                        mine.lowest = low < mine.lowest ? low : mine.lowest;
+                        mine.highest = high > mine.highest ? high : mine.highest;
+                        mine.middles += ((long long)f + l) >> 1;
+                        mine.rows += 1;
+                    }
+                }
+            }
+        }
+        mine.lowest = waveMin(mine.lowest);
+        mine.highest = waveMax(mine.highest);
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) {
+            mine.rows += laneXor(mine.rows, m);
+            const int lowHalf = laneXor((int)(unsigned)(mine.middles & 0xffffffffll), m);
+            const int highHalf = laneXor((int)(mine.middles >> 32), m);
+            mine.middles += ((long long)highHalf << 32) | (unsigned)lowHalf;
+        }
+        ColumnProbe* seen = ldsArray<ColumnProbe, WAVES>();
+        if (lane == 0)
+            seen[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        ColumnProbe all{0x7fffffff, -0x7fffffff - 1, 0, 0};
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const ColumnProbe other = seen[w];
+            all.lowest = other.lowest < all.lowest ? other.lowest : all.lowest;
+            all.highest = other.highest > all.highest ? other.highest : all.highest;
+            all.rows += other.rows;
+            all.middles += other.middles;
+        }
+        if (all.rows > 0 && all.lowest >= 0) {
+            const long long span = (long long)all.highest - all.lowest + 1;
+            if (span <= TILE_ELEMS) {
+                tileBase = all.lowest;
+                tileCount = (unsigned)span;
+            } else {
+                long long start = all.middles / all.rows - TILE_ELEMS / 2;
+                start = start < all.lowest ? all.lowest : start;
+                start = start + TILE_ELEMS > (long long)all.highest + 1 ? (long long)all.highest + 1 - TILE_ELEMS : start;
+                tileBase = (int)start;
+                tileCount = TILE_ELEMS;
+            }
+        }
+        /* coalesced copy: 16-byte pieces (global memory takes them at any element address), 4 per lane in flight */
+        constexpr int PIECE = 16 / (int)sizeof(T);
+        const T* __restrict__ from = x + tileBase;
+        const unsigned pieces = tileCount / PIECE;
+        for (unsigned p0 = threadIdx.x; p0 < pieces; p0 += 4u * BLOCK) {
+            Pack<T, PIECE> w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (p0 + q * BLOCK < pieces)
+                    w[q] = loadPackElementAligned<T, PIECE>(from + (size_t)(p0 + q * BLOCK) * PIECE);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (p0 + q * BLOCK < pieces)
+                    storePack<T, PIECE>(tile + (size_t)(p0 + q * BLOCK) * PIECE, w[q]);
+        }
+        if (pieces * PIECE + threadIdx.x < tileCount)
+            tile[pieces * PIECE + threadIdx.x] = from[pieces * PIECE + threadIdx.x];
+        __syncthreads();
+    }
+
+    auto processGroup = [&](const long long group) {
+    const long long groupRow0 = group * GROUP_ROWS;
+    if (groupRow0 >= a.rows)
+        return; /* whole wavefront leaves together (the workgroup's barriers are behind it) */
     const long long row0 = groupRow0 + (long long)sub * RPL;
     const bool stripLive = row0 < a.rows;
 
@@ -174,6 +290,42 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
         len[t] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
         laneLongest = len[t] > laneLongest ? len[t] : laneLongest;
     }
+    /* DEEP: one very long row (or a hack of them, after the rows were ordered by length) would keep this wavefront
+     * streaming long after the rest of the grid has drained -- a single wavefront moves a few GB/s.  A 32-row
+     * sub-group deeper than deepCap therefore keeps only its first deepCap columns here; it registers itself in a
+     * deep queue and deepSpmvKernel, launched right behind this kernel, spreads the remaining columns -- in chunks,
+     * over the wavefronts of a workgroup -- adds the sums below and writes z.  A full queue: the sub-group stays here. */
+    int deepSlot = -1;
+    if constexpr (DEEP) {
+        static_assert(PH == 1, "the deep split is built for the shapes in which a lane walks whole rows");
+        constexpr int SUB = 32 / RPL; /* lanes that hold one 32-row sub-group */
+        int subDepth = laneLongest;
+#pragma unroll
+        for (int m = 1; m < SUB; m <<= 1) {
+            const int other = laneXor(subDepth, m);
+            subDepth = other > subDepth ? other : subDepth;
+        }
+        int slot = -1;
+        if (lane % SUB == 0 && subDepth > a.deepCap) {
+            /* queue = the workgroup of deepSpmvKernel that will finish this sub-group: consecutive sub-groups (the
+             * deepest ones, after an ordering by length) go to consecutive workgroups */
+            const int queue = (int)((row0 >> 5) % SPGPU_DEEP_QUEUES);
+            const int at = atomicAdd(&a.deepCounts[queue], 1);
+            if (at < SPGPU_DEEP_QUEUE_ENTRIES) {
+                slot = queue * SPGPU_DEEP_QUEUE_ENTRIES + at;
+                a.deepEntries[slot] = SpgpuDeepEntry{(int)row0, subDepth};
+            }
+        }
+        deepSlot = __shfl(slot, lane & ~(SUB - 1), kWave);
+        if (deepSlot >= 0) {
+            laneLongest = 0;
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                len[t] = len[t] < a.deepCap ? len[t] : a.deepCap;
+                laneLongest = len[t] > laneLongest ? len[t] : laneLongest;
+            }
+        }
+    }
     const int groupLongest = waveMax(laneLongest); /* wave-uniform trip count */
 
     T sum[RPL];
@@ -183,14 +335,6 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
 
     const T* __restrict__ vals = a.cM + slab;
     const int* __restrict__ idxs = a.rP + slab;
-    const T* __restrict__ x = a.x;
-
-    /* XTILE: x[tileBase .. tileBase + tileCount) lives in `tile` once the prologue below has run */
-    T* tile = nullptr;
-    int tileBase = 0;
-    unsigned tileCount = 0;
-    if constexpr (XTILE)
-        tile = ldsArray<T, TILE_ELEMS>();
 
     /* One stage = UNROLL slab columns per phase: the coefficient/index loads of a stage are
      * issued back to back (fetch), its x gathers and multiply-adds follow (consume).  With
@@ -321,82 +465,6 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
     if constexpr (PIPE) {
         Stage cur, nxt;
         fetch(0, cur);
-        if constexpr (XTILE) {
-            /* Which slice of x?  Every row is sampled at its first and its last entry (the extremes of a row whose
-             * columns ascend; any row order is still correct, entries outside the tile are gathered from global
-             * memory).  The first index is in the stage just requested; the last costs one more load per row, in the
-             * same round trip.  If the span of the workgroup's rows fits the tile it starts at the lowest column,
-             * otherwise it is centred on the mean of the rows' middles (a few far-away rows then do not drag it off). */
-            int lastIndex[RPL];
-#pragma unroll
-            for (int t = 0; t < RPL; ++t)
-                lastIndex[t] = (phase == 0 && len[t] > 0) ? idxs[t + (long long)(len[t] - 1) * a.idxStride] : 0;
-            ColumnProbe mine{0x7fffffff, -0x7fffffff - 1, 0, 0};
-#pragma unroll
-            for (int t = 0; t < RPL; ++t) {
-                if (phase == 0 && len[t] > 0) {
-                    const int first = cur.c[0].v[t] - a.baseIndex, last = lastIndex[t] - a.baseIndex;
-                    const int low = first < last ? first : last, high = first < last ? last : first;
-                    mine.lowest = low < mine.lowest ? low : mine.lowest;
-                    mine.highest = high > mine.highest ? high : mine.highest;
-                    mine.middles += ((long long)first + last) >> 1;
-                    mine.rows += 1;
-                }
-            }
-            mine.lowest = waveMin(mine.lowest);
-            mine.highest = waveMax(mine.highest);
-#pragma unroll
-            for (int m = 1; m < kWave; m <<= 1) {
-                mine.rows += laneXor(mine.rows, m);
-                const int lowHalf = laneXor((int)(unsigned)(mine.middles & 0xffffffffll), m);
-                const int highHalf = laneXor((int)(mine.middles >> 32), m);
-                mine.middles += ((long long)highHalf << 32) | (unsigned)lowHalf;
-            }
-            ColumnProbe* seen = ldsArray<ColumnProbe, WAVES>();
-            if (lane == 0)
-                seen[threadIdx.x >> 6] = mine;
-            __syncthreads();
-            ColumnProbe all{0x7fffffff, -0x7fffffff - 1, 0, 0};
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const ColumnProbe other = seen[w];
-                all.lowest = other.lowest < all.lowest ? other.lowest : all.lowest;
-                all.highest = other.highest > all.highest ? other.highest : all.highest;
-                all.rows += other.rows;
-                all.middles += other.middles;
-            }
-            if (all.rows > 0 && all.lowest >= 0) {
-                const long long span = (long long)all.highest - all.lowest + 1;
-                if (span <= TILE_ELEMS) {
-                    tileBase = all.lowest;
-                    tileCount = (unsigned)span;
-                } else {
-                    long long start = all.middles / all.rows - TILE_ELEMS / 2;
-                    start = start < all.lowest ? all.lowest : start;
-                    start = start + TILE_ELEMS > (long long)all.highest + 1 ? (long long)all.highest + 1 - TILE_ELEMS : start;
-                    tileBase = (int)start;
-                    tileCount = TILE_ELEMS;
-                }
-            }
-            /* coalesced copy: 16-byte pieces (global memory takes them at any element address), 4 per lane in flight */
-            constexpr int PIECE = 16 / (int)sizeof(T);
-            const T* __restrict__ from = x + tileBase;
-            const unsigned pieces = tileCount / PIECE;
-            for (unsigned p0 = threadIdx.x; p0 < pieces; p0 += 4u * BLOCK) {
-                Pack<T, PIECE> w[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (p0 + q * BLOCK < pieces)
-                        w[q] = loadPackElementAligned<T, PIECE>(from + (size_t)(p0 + q * BLOCK) * PIECE);
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (p0 + q * BLOCK < pieces)
-                        storePack<T, PIECE>(tile + (size_t)(p0 + q * BLOCK) * PIECE, w[q]);
-            }
-            if (pieces * PIECE + threadIdx.x < tileCount)
-                tile[pieces * PIECE + threadIdx.x] = from[pieces * PIECE + threadIdx.x];
-            __syncthreads();
-        }
         /* one stage: `form` says how its x values are fetched */
         auto stage = [&](auto form) {
             if constexpr (PIPE == 2) {
@@ -521,6 +589,15 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
     if (phase != 0 || !stripLive)
         return;
 
+    if constexpr (DEEP) {
+        if (deepSlot >= 0) { /* raw sums: deepSpmvKernel finishes these rows */
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                a.deepPartials[(size_t)deepSlot * 32 + (size_t)((row0 + t) & 31)] = sum[t];
+            return;
+        }
+    }
+
     const bool hasBeta = isNotZero(a.beta);
     if (!a.rIdx && a.wideIO && row0 + RPL <= a.rows) {
         Pack<T, RPL> out;
@@ -546,7 +623,179 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
             }
         }
     }
+    }; /* processGroup */
+
+#pragma unroll 1
+    for (int turn = 0; turn < GPW; ++turn)
+        processGroup(groupOfTurn(turn));
 }
+
+/*
+ * The columns >= deepCap of the sub-groups (32 rows) the DEEP form of slabSpmvKernel registered.  Workgroup q owns
+ * queue q.  The remaining columns of a sub-group are cut into chunks of CHUNK columns; the (sub-group, chunk) items of
+ * the whole queue are dealt to the workgroup's wavefronts, WAVES per pass -- so a queue of many shallow sub-groups keeps
+ * every wavefront busy just as one very deep sub-group does.  A wavefront reads a chunk the way the format stores it:
+ * 32/RPL lanes with RPL rows each cover a slab column, PH = 64 / (32/RPL) columns per load instruction, UNROLL of them
+ * per stage.  Sum of one row: what slabSpmvKernel left in deepPartials, plus the chunk sums in chunk order; a chunk sum
+ * = its PH phase sums (each over ascending k) combined pairwise.  The oracle restates exactly this (orc_?spmv_deep).
+ * x comes from global memory: these are the few long rows, their own columns give them their locality.
+ * Only workgroup q reads or resets queue q, so nothing here depends on another workgroup.
+ */
+template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int CHUNK>
+__global__ __launch_bounds__(WAVES * kWave) void deepSpmvKernel(const SlabArgs<T> a)
+{
+    constexpr int LPC = 32 / RPL;    /* lanes per slab column of 32 rows */
+    constexpr int PH = kWave / LPC;  /* columns per wave-wide load */
+    constexpr int STEP = PH * UNROLL;
+    static_assert(CHUNK % STEP == 0, "a chunk is a whole number of stages");
+    constexpr int QE = SPGPU_DEEP_QUEUE_ENTRIES;
+    __shared__ T chunkSum[WAVES][32];
+    __shared__ T total[QE][32];
+    __shared__ int firstItem[QE + 1];
+    __shared__ SpgpuDeepEntry entry[QE];
+
+    const int queue = blockIdx.x;
+    const int registered = a.deepCounts[queue];
+    if (registered == 0)
+        return; /* the whole workgroup */
+    const int entries = registered < QE ? registered : QE;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane % LPC, phase = lane / LPC;
+
+    if (threadIdx.x < entries)
+        entry[threadIdx.x] = a.deepEntries[queue * QE + threadIdx.x];
+    for (int i = threadIdx.x; i < entries * 32; i += WAVES * kWave)
+        total[i >> 5][i & 31] = a.deepPartials[(size_t)queue * QE * 32 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int items = 0;
+        for (int e = 0; e < entries; ++e) {
+            firstItem[e] = items;
+            items += (entry[e].depth - a.deepCap + CHUNK - 1) / CHUNK;
+        }
+        firstItem[entries] = items;
+        a.deepCounts[queue] = 0; /* for the next call; this workgroup has its copy */
+    }
+    __syncthreads();
+    const int items = firstItem[entries];
+
+    for (int pass = 0; pass < items; pass += WAVES) {
+        const int item = pass + wave; /* wave-uniform */
+        if (item < items) {
+            int e = 0;
+            while (firstItem[e + 1] <= item)
+                ++e;
+            const int kFirst = a.deepCap + (item - firstItem[e]) * CHUNK;
+            const int kEnd = kFirst + CHUNK < entry[e].depth ? kFirst + CHUNK : entry[e].depth;
+            const long long row0 = (long long)entry[e].row0 + (long long)sub * RPL;
+            long long slab = 0;
+            int len[RPL];
+            int laneLongest = 0;
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                const long long r = row0 + t;
+                len[t] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+                len[t] = len[t] < kEnd ? len[t] : kEnd;
+                laneLongest = len[t] > laneLongest ? len[t] : laneLongest;
+            }
+            if (row0 < a.rows) {
+                if constexpr (IS_HELL) {
+                    const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
+                    const unsigned hack = r0 / hs;
+                    slab = (long long)a.hackOffsets[hack] + (r0 - hack * hs);
+                } else {
+                    slab = row0;
+                }
+            }
+            const T* __restrict__ vals = a.cM + slab;
+            const int* __restrict__ idxs = a.rP + slab;
+            T sum[RPL];
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                sum[t] = zeroOf<T>();
+
+            struct Stage {
+                Pack<T, RPL> v[UNROLL];
+                Pack<int, RPL> c[UNROLL];
+            };
+            auto fetch = [&](int kBase, Stage& s) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int k = kBase + u * PH + phase;
+                    if (k < laneLongest) {
+                        s.v[u] = loadPack<true, T, RPL>(vals + (long long)k * a.valStride);
+                        s.c[u] = loadPack<true, int, RPL>(idxs + (long long)k * a.idxStride);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < RPL; ++t) {
+                            s.v[u].v[t] = zeroOf<T>();
+                            s.c[u].v[t] = a.baseIndex;
+                        }
+                    }
+                }
+            };
+            Stage cur, nxt;
+            fetch(kFirst, cur);
+            for (int kBase = kFirst; kBase < kEnd; kBase += STEP) {
+                T xv[UNROLL][RPL];
+                bool use[UNROLL][RPL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int k = kBase + u * PH + phase;
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t) {
+                        const int col = cur.c[u].v[t] - a.baseIndex;
+                        use[u][t] = k < len[t] && col >= 0;
+                        xv[u][t] = a.x[use[u][t] ? col : 0];
+                    }
+                }
+                fetch(kBase + STEP, nxt); /* behind the gathers in vmcnt order: stays in flight while they are used */
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t)
+                        sum[t] = pick(use[u][t], mulAdd(cur.v[u].v[t], xv[u][t], sum[t]), sum[t]);
+                }
+                cur = nxt;
+            }
+#pragma unroll
+            for (int m = LPC; m < kWave; m <<= 1) {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    sum[t] = add(sum[t], laneXor(sum[t], m));
+            }
+            if (phase == 0) {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    chunkSum[wave][sub * RPL + t] = sum[t];
+            }
+        }
+        __syncthreads();
+        /* items are numbered sub-group by sub-group, chunks ascending: adding in item order is adding in chunk order */
+        if (threadIdx.x < 32) {
+            int e = 0;
+            for (int w = 0; w < WAVES && pass + w < items; ++w) {
+                while (firstItem[e + 1] <= pass + w)
+                    ++e;
+                total[e][threadIdx.x] = add(total[e][threadIdx.x], chunkSum[w][threadIdx.x]);
+            }
+        }
+        __syncthreads();
+    }
+
+    const bool hasBeta = isNotZero(a.beta);
+    for (int i = threadIdx.x; i < entries * 32; i += WAVES * kWave) {
+        const long long r = (long long)entry[i >> 5].row0 + (i & 31);
+        if (r < a.rows) {
+            const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+            a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, total[i >> 5][i & 31], a.beta, a.y[outRow])
+                                  : epilogue<false>(a.alpha, total[i >> 5][i & 31], a.beta, zeroOf<T>());
+        }
+    }
+}
+
+#include "ragged_spmv.hip.h"
 
 /* ---- host side ----------------------------------------------------------- */
 
@@ -576,31 +825,46 @@ static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
  * rows (PH 1) with 4 slab columns per stage -- half the stage of the gather kernel: LDS gathers are short, and at 8 the
  * kernel needs 148 VGPRs, which leaves room for one 512-lane workgroup per CU only.  Shape 0 is the default; the
  * others exist for A/B runs (SPGPU_X_TILE_SHAPE):
- *   1  one wavefront per 32-row group (PH = 2 * RPL, 2 columns per stage), 512 lanes, 64 KiB
- *   2  1024 lanes, 128 KiB (one workgroup per CU)      3  256 lanes, 32 KiB
+ *   1  one wavefront per 32-row group (PH = 2 * RPL, 2 columns per stage), 512 lanes, 64 KiB  (no deep split)
+ *   2  512 lanes, 64 KiB      3  256 lanes, 48 KiB
  * The coefficient/index streams always carry the non-temporal hint here. */
-template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool TAIL, int BLOCK, int TILE_BYTES>
-static void launchTile(hipStream_t stream, const SlabArgs<T>& a)
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool TAIL, int BLOCK, int TILE_BYTES, bool DEEP, int GPW = 1>
+static void launchShape(hipStream_t stream, const SlabArgs<T>& a)
 {
     constexpr int GROUP_ROWS = (kWave / PH) * RPL;
     constexpr int WAVES = BLOCK / kWave;
     const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
-    const unsigned blocks = (unsigned)((groups + WAVES - 1) / WAVES);
-    hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, 2, TAIL, 0, false, BLOCK, TILE_BYTES>), dim3(blocks),
-                       dim3(BLOCK), 0, stream, a);
+    const unsigned blocks = (unsigned)((groups + WAVES * GPW - 1) / (WAVES * GPW));
+    hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, 2, TAIL, 0, false, BLOCK, TILE_BYTES, DEEP, GPW>),
+                       dim3(blocks), dim3(BLOCK), 0, stream, a);
 }
 
-template <typename T, int RPL, bool IS_HELL>
+template <typename T, int RPL, bool IS_HELL, bool DEEP>
 static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
 {
-    constexpr int PH1 = sizeof(T) == 16 ? 2 : 1; /* 16-byte elements keep the 2-phase shape of their default kernel */
-    constexpr bool TAIL = sizeof(T) != 16;
+    constexpr int PH1 = (sizeof(T) == 16 && !DEEP) ? 2 : 1; /* 16-byte elements keep the 2-phase shape of their default kernel */
+    constexpr bool TAIL = PH1 == 1;
     switch (shape) {
-    case 1: launchTile<T, RPL, (RPL > 1 ? 2 * RPL : 2), IS_HELL, (RPL > 1 ? 2 : 4), TAIL, 512, 65536>(stream, a); break;
-    case 2: launchTile<T, RPL, PH1, IS_HELL, 4, TAIL, 1024, 131072>(stream, a); break;
-    case 3: launchTile<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 32768>(stream, a); break;
-    default: launchTile<T, RPL, PH1, IS_HELL, 4, TAIL, 512, 65536>(stream, a); break;
+    case 1:
+        if constexpr (!DEEP) {
+            launchShape<T, RPL, (RPL > 1 ? 2 * RPL : 2), IS_HELL, (RPL > 1 ? 2 : 4), (RPL > 1), 512, 65536, false>(stream, a);
+            break;
+        }
+        [[fallthrough]];
+    case 2: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 512, 65536, DEEP>(stream, a); break;
+    case 3: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 49152, DEEP, 2>(stream, a); break;
+    case 4: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 65536, DEEP, 2>(stream, a); break;
+    case 5: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 512, 65536, DEEP, 2>(stream, a); break;
+    default: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 32768, DEEP>(stream, a); break;
     }
+}
+
+/* Right behind a DEEP kernel: a workgroup per queue; the workgroups whose queue is empty leave at once. */
+template <typename T, int RPL, bool IS_HELL>
+static void launchDeep(hipStream_t stream, const SlabArgs<T>& a)
+{
+    constexpr int UNROLL = 2; /* <= 64 VGPRs: all the queues' workgroups are resident at once */
+    hipLaunchKernelGGL((deepSpmvKernel<T, RPL, IS_HELL, UNROLL, 8, 128>), dim3(SPGPU_DEEP_QUEUES), dim3(8 * kWave), 0, stream, a);
 }
 
 template <typename T, bool IS_HELL>
@@ -654,6 +918,41 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     if (tune->xTile >= 0)
         form = tune->xTile ? SPGPU_SPMV_FORM_XTILE : (form == SPGPU_SPMV_FORM_XTILE ? SPGPU_SPMV_FORM_AUTO : form);
     const bool tiled = form == SPGPU_SPMV_FORM_XTILE && (variant == 13 || variant == 21 || variant == 22);
+    /* Deep split (see slabSpmvKernel, DEEP): on when the caller passes a row order -- rows ordered by length are what
+     * one does to a ragged matrix, and then whole hacks are deep -- or when SPGPU_DEEP_SPLIT says so. */
+    bool deepSplit = (tune->deepSplit >= 0 ? tune->deepSplit != 0 : a.rIdx != nullptr) && wideOk &&
+                     (variant == 21 || variant == 22);
+    a.deepCap = tune->deepCap > 0 ? tune->deepCap : 128;
+    a.deepCounts = nullptr;
+    a.deepEntries = nullptr;
+    a.deepPartials = nullptr;
+    if (deepSplit) {
+        void* partials = nullptr;
+        if (spgpuDeepScratch(handle, &a.deepCounts, &a.deepEntries, &partials) == SPGPU_SUCCESS)
+            a.deepPartials = static_cast<T*>(partials);
+        else
+            deepSplit = false;
+    }
+    if (deepSplit && tune->ragged != 0) {
+        /* the queue-driven kernel for rows ordered by length (ragged_spmv.hip.h); x through an LDS tile unless the
+         * caller asked for plain gathers */
+        a.wideIO = 0;
+        a.feedback = nullptr;
+        launchRagged<T, WIDE, IS_HELL, true>(stream, a, tune->raggedShape, form != SPGPU_SPMV_FORM_GATHER);
+        launchDeep<T, WIDE, IS_HELL>(stream, a);
+        return;
+    }
+    if (deepSplit) {
+        /* shapes in which a lane walks whole rows, for every type; the strip form does not apply to ordered rows */
+        a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
+        a.feedback = nullptr;
+        if (tiled)
+            launchTiled<T, WIDE, IS_HELL, true>(stream, a, tune->xTileShape);
+        else
+            launchShape<T, WIDE, 1, IS_HELL, (sizeof(T) == 8 ? 8 : 4), true, kBlockThreads, 0, true>(stream, a);
+        launchDeep<T, WIDE, IS_HELL>(stream, a);
+        return;
+    }
     bool strips = false;
     a.feedback = nullptr;
     if (!narrowVariant && WIDE > 1 && !tiled) {
@@ -692,7 +991,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 17: launchSlab<T, WIDE, 1, IS_HELL, 8, 1, true>(stream, a, nt); break;
             case 22:
                 if (tiled)
-                    launchTiled<T, WIDE, IS_HELL>(stream, a, tune->xTileShape);
+                    launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
                 else if (strips)
                     launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true, 0, true>(stream, a, nt);
                 else
@@ -701,7 +1000,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;
             default: /* 21 */
                 if (tiled)
-                    launchTiled<T, WIDE, IS_HELL>(stream, a, tune->xTileShape);
+                    launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
                 else if (strips)
                     launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true, 0, true>(stream, a, nt);
                 else
@@ -722,7 +1021,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
 #endif
     default: /* 13 */
         if (tiled)
-            launchTiled<T, 1, IS_HELL>(stream, a, tune->xTileShape);
+            launchTiled<T, 1, IS_HELL, false>(stream, a, tune->xTileShape);
         else
             launchSlab<T, 1, 2, IS_HELL, 4, 2>(stream, a, nt);
         break;

@@ -1,0 +1,342 @@
+/*
+ * ELL / HELL SpMV for matrices whose rows were ORDERED BY LENGTH (rIdx given: spgpuOellOrderDevice, ellToOell) --
+ * the north_star target, power-law row lengths.  Included by ellpack_spmv.hip (namespace spgpu, after SlabArgs).
+ *
+ * What is different from slabSpmvKernel: there a wavefront owns a fixed block of rows, which is right when rows are
+ * about equally long.  After an ordering by length the depth changes along the rows -- steeply at the head of every
+ * window -- and a workgroup whose wavefronts own fixed rows waits for its deepest ones with the LDS tile and the
+ * wavefront slots of the others idle.  Here a workgroup owns SUBS sub-groups of 32 rows and its wavefronts take them
+ * from a queue, deepest first (that is the order the rows are in), one wavefront per sub-group:
+ *
+ *   - "one wavefront per hack": 32/RPL lanes with RPL rows each cover a slab column, PH = 64 / (32/RPL) columns per
+ *     load instruction (1 KiB contiguous for hackSize 32), UNROLL of them per stage; the PH phase sums of a row are
+ *     combined with lane-xor shuffles.  Summation order = the reference's multi-thread-per-row order generalised to
+ *     PH phases (hell_spmv_base_template.cuh:59-101): phase p adds the entries k = p (mod PH) in ascending k, the
+ *     phase sums are combined pairwise -- orc_?hellspmv / orc_?ellspmv with phases = PH.
+ *   - row lengths and slab bases of all the workgroup's rows sit in LDS, so a wavefront that finishes a sub-group
+ *     knows the addresses of the next one at once: the first stage of the next sub-group is requested during the last
+ *     stage of the current one, and the stream never stops for a dependent look-up.
+ *   - the slice of x the workgroup's rows touch is staged in LDS (as in the x-tile form of slabSpmvKernel); entries
+ *     outside it are gathered from global memory.
+ *   - sub-groups deeper than deepCap keep their first deepCap columns here and hand the rest to deepSpmvKernel
+ *     through the deep queues (see slabSpmvKernel, DEEP).
+ *
+ * Algorithmic bytes as for slabSpmvKernel, plus 4 per row for rIdx.
+ */
+
+template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int TILE_BYTES, int SUBS, bool DEEP>
+__global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs<T> a)
+{
+    constexpr int LPC = 32 / RPL;   /* lanes per slab column of a sub-group */
+    constexpr int PH = kWave / LPC; /* slab columns per wave-wide load */
+    constexpr int STEP = PH * UNROLL;
+    constexpr int BLOCK = WAVES * kWave;
+    constexpr int ROWS = SUBS * 32;
+    constexpr bool XTILE = TILE_BYTES > 0;
+    constexpr int TILE_ELEMS = XTILE ? TILE_BYTES / (int)sizeof(T) : 1;
+    static_assert(SUBS >= WAVES, "every wavefront starts with a sub-group of its own");
+
+    __shared__ __attribute__((aligned(16))) T tile[TILE_ELEMS];
+    __shared__ int lens[ROWS];        /* row lengths as walked here (deep sub-groups: cut at deepCap) */
+    __shared__ int bases[ROWS / RPL]; /* first slot of every RPL-row strip, in elements */
+    __shared__ int depths[SUBS];      /* longest walked row of every sub-group */
+    __shared__ int deepSlots[SUBS];   /* its entry in the deep queues, or -1 */
+    __shared__ int nextItem;
+    __shared__ ColumnProbe seen[WAVES];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane % LPC, phase = lane / LPC;
+    const long long blockRow0 = (long long)blockIdx.x * ROWS;
+    const T* __restrict__ x = a.x;
+
+    /* ---- 1: row lengths and strip bases of the whole workgroup --------------------------------------------------- */
+    for (int i = threadIdx.x; i < ROWS; i += BLOCK) {
+        const long long r = blockRow0 + i;
+        lens[i] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+    }
+    for (int i = threadIdx.x; i < ROWS / RPL; i += BLOCK) {
+        const long long r0 = blockRow0 + (long long)i * RPL;
+        int at = 0;
+        if (r0 < a.rows) {
+            if constexpr (IS_HELL) {
+                const unsigned u0 = (unsigned)r0, hs = (unsigned)a.hackSize;
+                at = a.hackOffsets[u0 / hs] + (int)(u0 % hs);
+            } else {
+                at = (int)r0;
+            }
+        }
+        bases[i] = at;
+    }
+    if (threadIdx.x == 0)
+        nextItem = WAVES; /* the first WAVES sub-groups are dealt out statically */
+    __syncthreads();
+
+    /* ---- 2: depth of every sub-group; the deep ones register and are cut at deepCap ------------------------------ */
+    for (int s = wave; s < SUBS; s += WAVES) {
+        const int mine = lane < 32 ? lens[s * 32 + lane] : 0;
+        const int depth = waveMax(mine);
+        int slot = -1;
+        if constexpr (DEEP) {
+            if (depth > a.deepCap) {
+                if (lane == 0) {
+                    const long long sub0 = (blockRow0 >> 5) + s;
+                    const int queue = (int)(sub0 % SPGPU_DEEP_QUEUES);
+                    const int at = atomicAdd(&a.deepCounts[queue], 1);
+                    if (at < SPGPU_DEEP_QUEUE_ENTRIES) {
+                        slot = queue * SPGPU_DEEP_QUEUE_ENTRIES + at;
+                        a.deepEntries[slot] = SpgpuDeepEntry{(int)(sub0 << 5), depth};
+                    }
+                }
+                slot = __shfl(slot, 0, kWave);
+                if (slot >= 0 && lane < 32 && mine > a.deepCap)
+                    lens[s * 32 + lane] = a.deepCap;
+            }
+        }
+        if (lane == 0) {
+            depths[s] = (slot >= 0 && depth > a.deepCap) ? a.deepCap : depth;
+            deepSlots[s] = slot;
+        }
+    }
+    __syncthreads();
+
+    /* ---- the per-sub-group state of a lane, and the stage loads --------------------------------------------------- */
+    struct Item {
+        long long slab; /* first slot of this lane's strip */
+        int len[RPL];
+        int longest;    /* of this lane's rows */
+        int depth;      /* of the sub-group (wave-uniform) */
+    };
+    struct Stage {
+        Pack<T, RPL> v[UNROLL];
+        Pack<int, RPL> c[UNROLL];
+    };
+    auto loadItem = [&](int s, Item& it) {
+        it.slab = bases[s * LPC + sub];
+        it.longest = 0;
+#pragma unroll
+        for (int t = 0; t < RPL; ++t) {
+            it.len[t] = lens[s * 32 + sub * RPL + t];
+            it.longest = it.len[t] > it.longest ? it.len[t] : it.longest;
+        }
+        it.depth = depths[s];
+    };
+    auto fetch = [&](const Item& it, int kBase, Stage& st) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = kBase + u * PH + phase;
+            if (k < it.longest) {
+                st.v[u] = loadPack<true, T, RPL>(a.cM + it.slab + (long long)k * a.valStride);
+                st.c[u] = loadPack<true, int, RPL>(a.rP + it.slab + (long long)k * a.idxStride);
+            } else {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    st.v[u].v[t] = zeroOf<T>();
+                    st.c[u].v[t] = a.baseIndex;
+                }
+            }
+        }
+    };
+
+    /* the wavefront's first sub-group: its first stage is on its way while the tile is being placed and filled */
+    int s = wave;
+    Item now, then;
+    Stage cur, nxt;
+    loadItem(s, now);
+    fetch(now, 0, cur);
+
+    /* ---- 3: which slice of x?  (see slabSpmvKernel, XTILE) ------------------------------------------------------- */
+    int tileBase = 0;
+    unsigned tileCount = 0;
+    if constexpr (XTILE) {
+        ColumnProbe mine{0x7fffffff, -0x7fffffff - 1, 0, 0};
+        for (int i = threadIdx.x; i < ROWS; i += BLOCK) {
+            const int len = lens[i];
+            if (len > 0) {
+                const long long at = (long long)bases[i / RPL] + i % RPL;
+                const int f = a.rP[at] - a.baseIndex;
+                const int l = a.rP[at + (long long)(len - 1) * a.idxStride] - a.baseIndex;
+                const int low = f < l ? f : l, high = f < l ? l : f;
+                mine.lowest = low < mine.lowest ? low : mine.lowest;
+                mine.highest = high > mine.highest ? high : mine.highest;
+                mine.middles += ((long long)f + l) >> 1;
+                mine.rows += 1;
+            }
+        }
+        mine.lowest = waveMin(mine.lowest);
+        mine.highest = waveMax(mine.highest);
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) {
+            mine.rows += laneXor(mine.rows, m);
+            const int lowHalf = laneXor((int)(unsigned)(mine.middles & 0xffffffffll), m);
+            const int highHalf = laneXor((int)(mine.middles >> 32), m);
+            mine.middles += ((long long)highHalf << 32) | (unsigned)lowHalf;
+        }
+        if (lane == 0)
+            seen[wave] = mine;
+        __syncthreads();
+        ColumnProbe all{0x7fffffff, -0x7fffffff - 1, 0, 0};
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const ColumnProbe other = seen[w];
+            all.lowest = other.lowest < all.lowest ? other.lowest : all.lowest;
+            all.highest = other.highest > all.highest ? other.highest : all.highest;
+            all.rows += other.rows;
+            all.middles += other.middles;
+        }
+        if (all.rows > 0 && all.lowest >= 0) {
+            const long long span = (long long)all.highest - all.lowest + 1;
+            if (span <= TILE_ELEMS) {
+                tileBase = all.lowest;
+                tileCount = (unsigned)span;
+            } else {
+                long long start = all.middles / all.rows - TILE_ELEMS / 2;
+                start = start < all.lowest ? all.lowest : start;
+                start = start + TILE_ELEMS > (long long)all.highest + 1 ? (long long)all.highest + 1 - TILE_ELEMS : start;
+                tileBase = (int)start;
+                tileCount = TILE_ELEMS;
+            }
+        }
+        constexpr int PIECE = 16 / (int)sizeof(T);
+        const T* __restrict__ from = x + tileBase;
+        const unsigned pieces = tileCount / PIECE;
+        for (unsigned p0 = threadIdx.x; p0 < pieces; p0 += 4u * BLOCK) {
+            Pack<T, PIECE> w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (p0 + q * BLOCK < pieces)
+                    w[q] = loadPackElementAligned<T, PIECE>(from + (size_t)(p0 + q * BLOCK) * PIECE);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (p0 + q * BLOCK < pieces)
+                    storePack<T, PIECE>(tile + (size_t)(p0 + q * BLOCK) * PIECE, w[q]);
+        }
+        if (pieces * PIECE + threadIdx.x < tileCount)
+            tile[pieces * PIECE + threadIdx.x] = from[pieces * PIECE + threadIdx.x];
+        __syncthreads();
+    }
+
+    /* ---- 4: sub-groups from the queue ----------------------------------------------------------------------------- */
+    auto grab = [&]() -> int {
+        int got = 0;
+        if (lane == 0)
+            got = atomicAdd(&nextItem, 1);
+        return __builtin_amdgcn_readfirstlane(got);
+    };
+    int sThen = grab(); /* known one sub-group ahead, so that its first stage can be requested in time */
+    const bool hasBeta = isNotZero(a.beta);
+
+    while (s < SUBS) {
+        T sum[RPL];
+#pragma unroll
+        for (int t = 0; t < RPL; ++t)
+            sum[t] = zeroOf<T>();
+        const int stages = now.depth > 0 ? (now.depth + STEP - 1) / STEP : 1; /* an empty sub-group still hands over */
+        for (int stage = 0; stage < stages; ++stage) {
+            const int kBase = stage * STEP;
+            T xv[UNROLL][RPL];
+            bool use[UNROLL][RPL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = kBase + u * PH + phase;
+                if constexpr (XTILE) {
+                    bool outside = false;
+                    unsigned at[RPL];
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t) {
+                        const int col = cur.c[u].v[t] - a.baseIndex;
+                        use[u][t] = k < now.len[t] && col >= 0;
+                        at[t] = (unsigned)(col - tileBase);
+                        const bool inside = at[t] < tileCount;
+                        outside |= use[u][t] && !inside;
+                        xv[u][t] = tile[inside ? at[t] : 0u];
+                    }
+                    if (__ballot(outside) != 0ull) {
+#pragma unroll
+                        for (int t = 0; t < RPL; ++t) {
+                            if (use[u][t] && at[t] >= tileCount)
+                                xv[u][t] = x[cur.c[u].v[t] - a.baseIndex];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t) {
+                        const int col = cur.c[u].v[t] - a.baseIndex;
+                        use[u][t] = k < now.len[t] && col >= 0;
+                        xv[u][t] = x[use[u][t] ? col : 0];
+                    }
+                }
+            }
+            /* behind the x reads in issue order: the next stage of this sub-group, or the first of the next one
+             * (one fetch, its source chosen by a wavefront-uniform test: two fetches cost 40 VGPRs) */
+            const bool lastStage = stage + 1 >= stages;
+            if (lastStage) {
+                if (sThen < SUBS)
+                    loadItem(sThen, then);
+                else
+                    then.longest = 0; /* nothing follows: the fetch below loads nothing */
+            }
+            Item from = now;
+            if (lastStage)
+                from = then;
+            fetch(from, lastStage ? 0 : kBase + STEP, nxt);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    sum[t] = pick(use[u][t], mulAdd(cur.v[u].v[t], xv[u][t], sum[t]), sum[t]);
+            }
+            cur = nxt;
+        }
+#pragma unroll
+        for (int m = LPC; m < kWave; m <<= 1) {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                sum[t] = add(sum[t], laneXor(sum[t], m));
+        }
+        if (phase == 0) {
+            const int deepSlot = deepSlots[s];
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                const long long r = blockRow0 + s * 32 + sub * RPL + t;
+                if (r < a.rows) {
+                    if (DEEP && deepSlot >= 0) {
+                        a.deepPartials[(size_t)deepSlot * 32 + (size_t)(sub * RPL + t)] = sum[t];
+                    } else {
+                        const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+                        a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
+                                              : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
+                    }
+                }
+            }
+        }
+        s = sThen;
+        now = then;
+        sThen = grab();
+    }
+}
+
+#ifndef SPGPU_RAGGED_UNROLL
+#define SPGPU_RAGGED_UNROLL(RPL) 2 /* wave-wide loads per stage (each PH slab columns) */
+#endif
+/* Shapes (SPGPU_RAGGED_SHAPE; 0 is the default): workgroup lanes / tile / sub-groups per workgroup. */
+template <typename T, int RPL, bool IS_HELL, bool DEEP>
+static void launchRagged(hipStream_t stream, const SlabArgs<T>& a, int shape, bool tiled)
+{
+    constexpr int UNROLL = SPGPU_RAGGED_UNROLL(RPL);
+    const long long subs = ((long long)a.rows + 31) / 32;
+#define SPGPU_RAGGED(WAVES, TILE, SUBS)                                                                               \
+    hipLaunchKernelGGL((raggedSpmvKernel<T, RPL, IS_HELL, UNROLL, WAVES, TILE, SUBS, DEEP>),                          \
+                       dim3((unsigned)((subs + (SUBS) - 1) / (SUBS))), dim3((WAVES) * kWave), 0, stream, a)
+    if (!tiled) {
+        SPGPU_RAGGED(4, 0, 16);
+        return;
+    }
+    switch (shape) {
+    case 1: SPGPU_RAGGED(8, 65536, 64); break;
+    case 2: SPGPU_RAGGED(4, 49152, 32); break;
+    case 3: SPGPU_RAGGED(4, 32768, 16); break;
+    default: SPGPU_RAGGED(8, 65536, 32); break;
+    }
+#undef SPGPU_RAGGED
+}

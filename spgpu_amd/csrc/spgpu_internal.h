@@ -32,6 +32,7 @@ typedef struct SpgpuPrivateHandle {
     unsigned formNext;
     pthread_mutex_t formLock; /* guards formKey / formRows / formNext */
     int spmvForm;             /* SPGPU_SPMV_FORM_* set by spgpuSetSpmvForm (atomic) */
+    void* deepScratch;        /* device: SpgpuDeepQueue | entries | partials; NULL until first needed */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8
 #define SPGPU_FEEDBACK_SAMPLES 4
@@ -40,6 +41,19 @@ static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
 {
     return (SpgpuPrivateHandle*)(void*)h;
 }
+
+/* Deep queues of the ELL/HELL SpMV (csrc/ellpack_spmv.hip, DEEP form): device memory owned by the handle, allocated on
+ * the first call that needs it.  SPGPU_DEEP_QUEUES queues of SPGPU_DEEP_QUEUE_ENTRIES entries; queue q belongs to
+ * workgroup q of deepSpmvKernel, which empties it.  One SpMV of a handle uses the queues at a time (calls on one stream
+ * do, in order). */
+typedef struct SpgpuDeepEntry {
+    int row0;  /* first row of the 32-row sub-group (a multiple of 32) */
+    int depth; /* its longest row */
+} SpgpuDeepEntry;
+#define SPGPU_DEEP_QUEUES 1024
+#define SPGPU_DEEP_QUEUE_ENTRIES 32
+/* Device pointers of the queues (counts, entries, 32 * 16 bytes of row sums per entry), or SPGPU_OUTOFMEMORY. */
+spgpuStatus_t spgpuDeepScratch(spgpuHandle_t h, int** counts, SpgpuDeepEntry** entries, void** partials);
 
 /* With -DSPGPU_DEBUG every launch is followed by a synchronising error check
  * that prints and exits, as the reference does under -DDEBUG
@@ -64,6 +78,10 @@ typedef struct SpgpuTuning {
     int xStrips;     /* -1: by feedback */
     int xTile;       /* -1: by the handle's hint */
     int xTileShape;  /* 0 */
+    int deepSplit;   /* -1: when rIdx is given */
+    int deepCap;     /* 128 */
+    int ragged;      /* 1: the queue-driven kernel where the deep split is on */
+    int raggedShape; /* 0 */
     int l1Nt;        /* -1: by size */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);

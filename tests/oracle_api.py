@@ -416,27 +416,63 @@ for _L, _T in SCALAR.items():
     _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32, i32]
 
 
+for _L, _T in SCALAR.items():
+    _f = getattr(orc, f"orc_{_LOW[_L]}spmv_deep")
+    _f.restype = None
+    _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32, i32,
+                   i32, i32, i32]
+
+DEEP_CAP = 128   # SPGPU_DEEP_CAP default
+# deepSpmvKernel (csrc/ellpack_spmv.hip launchDeep): phases = 64 / (32 / rows per lane); chunks of 128 columns
+DEEP_SHAPE = {"S": dict(deep_phases=8, deep_chunk=128), "D": dict(deep_phases=4, deep_chunk=128),
+              "C": dict(deep_phases=4, deep_chunk=128), "Z": dict(deep_phases=2, deep_chunk=128)}
+
+
 def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_rows=128, rows_per_lane=2, step=8,
-              tail_lanes=16, phases=1):
-    """HELL (dict has hack_offsets) or ELL SpMV in the summation order of the tail-mode slab kernel."""
+              tail_lanes=16, phases=1, deep_cap=0, deep_phases=1, deep_chunk=1):
+    """HELL (dict has hack_offsets) or ELL SpMV in the summation order of the tail-mode slab kernel; deep_cap > 0: with
+    the deep split (32-row sub-groups deeper than deep_cap finished by deepSpmvKernel)."""
     L = mat["letter"]
     z = np.zeros(mat["rows"], NP_DTYPE[L]) if y is None else np.array(y, NP_DTYPE[L], copy=True)
     yy = None if y is None else np.ascontiguousarray(y, NP_DTYPE[L])
     ri = None if r_idx is None else np.ascontiguousarray(r_idx, np.int32)
     is_hell = "hack_offsets" in mat
     rs = mat["row_lengths"] if (is_hell or with_row_sizes) else None
-    getattr(orc, f"orc_{_LOW[L]}spmv_tail")(
+    getattr(orc, f"orc_{_LOW[L]}spmv_deep")(
         _p(z), _p(yy), scalar(L, alpha), _p(mat["values"]), _p(mat["indices"]), mat["hack_size"] if is_hell else 0,
         _p(mat["hack_offsets"]) if is_hell else None, 0 if is_hell else mat["pitch"], 0 if is_hell else mat["pitch"],
         _p(rs), 0 if is_hell else mat["max_row"], _p(ri), mat["rows"], _p(np.ascontiguousarray(x, NP_DTYPE[L])),
-        scalar(L, beta), mat["base"], group_rows, rows_per_lane, step, tail_lanes, phases)
+        scalar(L, beta), mat["base"], group_rows, rows_per_lane, step, tail_lanes, phases, deep_cap, deep_phases, deep_chunk)
     return z
+
+
+def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0):
+    """spmv_tail parameters of the kernel the library runs for (type, x form, deep split): csrc/ellpack_spmv.hip
+    launchSlabFamily / launchTiled.  None for the shapes without a tail (complex fp64 outside the deep split: 2 phases)."""
+    rpl = {"S": 4, "D": 2, "C": 2, "Z": 1}[letter]
+    deep = dict(deep_cap=deep_cap, **DEEP_SHAPE[letter]) if deep_cap > 0 else {}
+    if form == "ragged":   # raggedSpmvKernel: one wavefront per 32-row sub-group, 64 / (32 / rpl) phases, no tail rows
+        phases = 2 * rpl
+        return dict(group_rows=32, rows_per_lane=rpl, step=phases * 2, tail_lanes=0, phases=phases, **deep)
+    if form == "xtile":
+        if tile_shape == 1 and not deep:
+            return dict(group_rows=32, rows_per_lane=rpl, step=4 * rpl, tail_lanes=16, phases=2 * rpl) if rpl > 1 else None
+        if letter == "Z" and not deep:
+            return None
+        return dict(group_rows=64 * rpl, rows_per_lane=rpl, step=4, tail_lanes=16, phases=1, **deep)
+    if deep:   # a lane walks whole rows: 8 columns per stage for 8-byte elements, 4 otherwise
+        return dict(group_rows=64 * rpl, rows_per_lane=rpl, step=8 if letter in "DC" else 4, tail_lanes=16, phases=1, **deep)
+    return dict(TAIL_SHAPE[letter]) if letter in TAIL_SHAPE else None
 
 
 def default_spmv(mat, x, y, alpha, beta, r_idx=None):
     """The oracle in the summation order of the library's DEFAULT kernel for this matrix's type
     (spgpu_amd/csrc/ellpack_spmv.hip launchSlabFamily): D/C one phase + tail, S 8 phases + tail, Z 2 phases."""
     L = mat["letter"]
+    if r_idx is not None:
+        # a row order selects the queue-driven kernel (ragged_spmv.hip.h) with the deep split: sub-groups deeper than
+        # 128 columns are finished by deepSpmvKernel
+        return spmv_tail(mat, x, y, alpha, beta, r_idx=r_idx, **slab_shape(L, "ragged", deep_cap=DEEP_CAP))
     if L in TAIL_SHAPE:
         return spmv_tail(mat, x, y, alpha, beta, r_idx=r_idx, **TAIL_SHAPE[L])
     phases = {"Z": 2}[L]

@@ -115,14 +115,9 @@ def test_coo_route_builds_the_ordered_hell(gpu, window, long_rows, base):
     assert h["rP"][:h["slots"]].cpu().numpy().tobytes() == hell["indices"].tobytes()
 
 
-# the x-tile kernels' summation orders (csrc/ellpack_spmv.hip launchTiled), as oracle_api.spmv_tail parameters
-def tile_shape(letter, shape):
-    rpl = {"S": 4, "D": 2, "C": 2, "Z": 1}[letter]
-    if letter == "Z":
-        return None  # two phases, no tail: plain 2-phase order
-    if shape == 1:
-        return dict(group_rows=32, rows_per_lane=rpl, step=2 * rpl * 2, tail_lanes=16, phases=2 * rpl)
-    return dict(group_rows=64 * rpl, rows_per_lane=rpl, step=4, tail_lanes=16, phases=1)
+def tile_shape(letter, shape, deep=True):
+    """spmv_tail parameters of the x-tile kernels; with a row order the deep split is on (cap 128)."""
+    return O.slab_shape(letter, "xtile", shape, deep_cap=O.DEEP_CAP if deep else 0)
 
 
 @pytest.mark.parametrize("shape", [0, 1, 2, 3])
@@ -134,7 +129,7 @@ def test_tile_form_through_ridx_bit_exact(gpu, tuning, letter, shape, window, lo
     in-place included; and equals the SAME product computed from the unordered matrix within the north_star bound."""
     import torch
     from spgpu_amd import capi, formats, synth
-    tuning(SPGPU_X_TILE_SHAPE=shape)
+    tuning(SPGPU_X_TILE_SHAPE=shape, SPGPU_RAGGED=0)
     n = 6000 + 13
     h, (r, c, v), lengths = _ordered_case(gpu, n, letter, window, long_rows, pattern=pattern)
     sub = dict(letter=letter, rows=n, values=h["cM"][:h["slots"]].cpu().numpy(), indices=h["rP"][:h["slots"]].cpu().numpy(),
@@ -195,7 +190,8 @@ def test_every_form_on_the_fixtures(gpu, name, form):
             if form != "xtile" and not (isinstance(mat, formats.DeviceEll) and mat.rS is None):
                 assert z.tobytes() == O.default_spmv(hell if isinstance(mat, formats.DeviceHell) else ell, g["x"], y, alpha, beta).tobytes()
             elif form == "xtile" and letter != "Z" and not (isinstance(mat, formats.DeviceEll) and mat.rS is None):
-                want = O.spmv_tail(hell if isinstance(mat, formats.DeviceHell) else ell, g["x"], y, alpha, beta, **tile_shape(letter, 0))
+                want = O.spmv_tail(hell if isinstance(mat, formats.DeviceHell) else ell, g["x"], y, alpha, beta,
+                                   **tile_shape(letter, 0, deep=False))
                 assert z.tobytes() == want.tobytes()
     finally:
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
@@ -219,3 +215,87 @@ def test_one_column_matrix_strips_form(gpu):
     finally:
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
     assert z.tobytes() == (v * 3.0).tobytes()
+
+
+@pytest.mark.parametrize("cap", [16, 128])
+@pytest.mark.parametrize("form", ["gather", "xtile"])
+@pytest.mark.parametrize("name", ["powerlaw_s_b1_h64", "powerlaw_d_b0_h32", "powerlaw_c_b0_h32", "powerlaw_z_b1_h64"])
+def test_deep_split_every_type_bit_exact(gpu, tuning, name, form, cap):
+    """The deep split on its own (SPGPU_DEEP_SPLIT=1, no row order): sub-groups deeper than the cap are finished by
+    deepSpmvKernel; HELL and ELL, all four types, hack 32 and 64, base 0 and 1, beta == 0 and != 0, against the oracle's
+    restatement of that order bit for bit and against the extended-precision fixtures."""
+    from spgpu_amd import capi, formats
+    from test_gpu_spmv import _load, _mats, _run, _within
+    tuning(SPGPU_DEEP_SPLIT=1, SPGPU_DEEP_CAP=cap, SPGPU_RAGGED=0)
+    g = _load(name)
+    letter, ell, hell, _ = _mats(g)
+    shape = O.slab_shape(letter, form, 0, deep_cap=cap)
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_XTILE if form == "xtile" else capi.FORM_GATHER)
+    try:
+        for beta in (0.0, g["beta"][()] if g["beta"][()] != 0 else 0.5):
+            y = g["y"] if beta != 0 else None
+            for mat, host in ((formats.DeviceHell(hell), hell), (formats.DeviceEll(ell), ell)):
+                z = _run(gpu, mat, g["x"], y, g["alpha"][()], beta)
+                assert z.tobytes() == O.spmv_tail(host, g["x"], y, g["alpha"][()], beta, **shape).tobytes()
+                if beta == g["beta"][()]:
+                    assert _within(z, g, letter) <= 1.0
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+
+
+def test_deep_queue_overflow_stays_correct(gpu, tuning):
+    """More deep sub-groups than the queue holds (cap 1 on 1.2 M rows of length 3: 37 500 sub-groups, capacity 32 768):
+    the surplus is summed by the main kernel; which sub-groups those are depends on scheduling, so the check is the
+    north_star bound, not bits -- and a second call must give the same rows the same treatment or not, still in bound."""
+    import torch
+    from spgpu_amd import capi, synth
+    tuning(SPGPU_DEEP_SPLIT=1, SPGPU_DEEP_CAP=1)
+    n = 1_200_000
+    h = synth.hell_uniform_on_device(n, 3, "banded", "D", 32, seed=3)
+    x = synth.device_vector(n, "D", 5)
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):
+        capi.hellspmv["D"](gpu, _dp(z), None, capi.scalar("D", 1.0), _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]),
+                           _dp(h["rS"]), None, 3, n, _dp(x), capi.scalar("D", 0.0), 0)
+        torch.cuda.synchronize()
+        cols = h["rP"].view(n // 32, 3, 32).to(torch.int64)
+        exact = (h["cM"].view(n // 32, 3, 32) * x[cols]).sum(dim=1).reshape(-1)
+        assert float((z - exact).abs().max()) <= 1e-12
+
+
+@pytest.mark.parametrize("shape,form", [(0, "auto"), (1, "auto"), (2, "auto"), (3, "auto"), (0, "gather")])
+@pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
+@pytest.mark.parametrize("window,long_rows,pattern,hack", [(512, 40, "near", 32), (0, 0, "near", 64), (1024, 0, "random", 32), (256, 100, "near", 96)])
+def test_ragged_kernel_through_ridx_bit_exact(gpu, tuning, letter, shape, form, window, long_rows, pattern, hack):
+    """The queue-driven kernel a row order selects (ragged_spmv.hip.h) with the deep split behind it: all four types,
+    hack sizes 32 / 64 / 96, every workgroup shape, tile and gathers, beta != 0 and in place; against the oracle in the
+    kernel's order (2 * rows-per-lane phases, chunks of 128 columns beyond the cap) bit for bit."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    tuning(SPGPU_RAGGED_SHAPE=shape)
+    n = 7000 + 5
+    real = {"S": "S", "D": "D", "C": "S", "Z": "D"}[letter]
+    lengths = np.minimum(synth.power_law_lengths(n, 12.0, 400, 9), 600)
+    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 300, real, seed=7)
+    if letter in "CZ":
+        vals_t = torch.complex(vals_t, torch.flip(vals_t, [0]))
+    h = formats.coo_to_ordered_hell_device(gpu, n, rows_t, cols_t, vals_t, letter, hack, window, long_rows)
+    sub = dict(letter=letter, rows=n, values=h["cM"][:h["slots"]].cpu().numpy(), indices=h["rP"][:h["slots"]].cpu().numpy(),
+               hack_offsets=h["hack_offsets"].cpu().numpy(), hack_size=hack, row_lengths=h["rS"][:n].cpu().numpy(), base=0)
+    r_idx = h["rIdx"].cpu().numpy()
+    x, y = synth.values_for(letter, 11, n), synth.values_for(letter, 12, n)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    shape_args = O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP)
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_GATHER if form == "gather" else capi.FORM_AUTO)
+    try:
+        for alpha, beta, in_place in ((1.0, 0.0, False), (-0.75, 0.5, False), (2.0, 1.0, True)):
+            dz = dy.clone() if in_place else torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            capi.hellspmv[letter](gpu, _dp(dz), _dp(dz if in_place else (dy if beta != 0 else None)), capi.scalar(letter, alpha),
+                                  _dp(h["cM"]), _dp(h["rP"]), hack, _dp(h["hack_offsets"]), _dp(h["rS"]), _dp(h["rIdx"]), 12, n,
+                                  _dp(dx), capi.scalar(letter, beta), 0)
+            torch.cuda.synchronize()
+            want = O.spmv_tail(sub, x, y if beta != 0 else None, alpha, beta, r_idx=r_idx, **shape_args)
+            assert dz.cpu().numpy().tobytes() == want.tobytes(), (alpha, beta, in_place)
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)

@@ -30,20 +30,21 @@ x = synth.device_vector(n, letter, 3)
 z = torch.zeros(n, dtype=x.dtype, device="cuda:0")
 xs = x.cpu().numpy()
 FORMS = {"auto": 0, "gather": 1, "strips": 2, "tile0": 3, "tile1": 3, "tile2": 3, "tile3": 3}
-# summation order of each form's kernel, for the oracle (tests/oracle_api.py spmv_tail)
-GATHER_SHAPE = O.TAIL_SHAPE[letter]
-TILE_SHAPES = {"D": {0: dict(group_rows=128, rows_per_lane=2, step=4, tail_lanes=16, phases=1),
-                     1: dict(group_rows=32, rows_per_lane=2, step=8, tail_lanes=16, phases=4),
-                     2: dict(group_rows=128, rows_per_lane=2, step=4, tail_lanes=16, phases=1),
-                     3: dict(group_rows=128, rows_per_lane=2, step=4, tail_lanes=16, phases=1)},
-               "S": {0: dict(group_rows=256, rows_per_lane=4, step=4, tail_lanes=16, phases=1),
-                     1: dict(group_rows=32, rows_per_lane=4, step=16, tail_lanes=16, phases=8),
-                     2: dict(group_rows=256, rows_per_lane=4, step=4, tail_lanes=16, phases=1),
-                     3: dict(group_rows=256, rows_per_lane=4, step=4, tail_lanes=16, phases=1)}}[letter]
+DEEP_CAP = int(os.environ.get("SPGPU_DEEP_CAP", "128"))
+
+
+def shape_of(form, ordered):
+    """spmv_tail parameters of the kernel that runs (tests/oracle_api.py slab_shape); a row order switches the deep split on"""
+    deep = DEEP_CAP if (ordered and os.environ.get("SPGPU_DEEP_SPLIT", "-1") != "0") or os.environ.get("SPGPU_DEEP_SPLIT") == "1" else 0
+    if form.startswith("ragged"):
+        return O.slab_shape(letter, "ragged", 0, deep_cap=deep)
+    if form.startswith("tile"):
+        return O.slab_shape(letter, "xtile", int(form[4:]), deep_cap=deep)
+    return O.slab_shape(letter, "gather", 0, deep_cap=deep)
 
 
 def check(h, form, windows=3, rows=2048):
-    shape = TILE_SHAPES[int(form[4:])] if form.startswith("tile") else GATHER_SHAPE
+    shape = shape_of(form, h.get("rIdx") is not None)
     step = max(1, (h["rows"] - rows) // max(windows - 1, 1))
     for w in range(windows):
         first = min(w * step, h["rows"] - rows) // 2048 * 2048
@@ -64,11 +65,13 @@ def run(h, label, forms):
     hacks = (rows + 31) // 32
     alg = h["nnz"] * (elem + 4) + rows * (4 + elem) + n * elem + hacks * 4 + (rows * 4 if h.get("rIdx") is not None else 0)
     call = lambda: capi.hellspmv[letter](handle, p(z), None, one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
-                                         p(h.get("rIdx")), 32, rows, p(x), zero, 0)
+                                         None if os.environ.get("EXP_DROP_RIDX") else p(h.get("rIdx")), 32, rows, p(x), zero, 0)
     for form in forms:
         os.environ["SPGPU_X_TILE_SHAPE"] = form[4:] if form.startswith("tile") else "0"
+        os.environ["SPGPU_RAGGED"] = "1" if form.startswith("ragged") else "0"      # raggedN: shape N with the tile; raggedg: gathers
+        os.environ["SPGPU_RAGGED_SHAPE"] = form[6:] if form.startswith("ragged") and form[6:].isdigit() else "0"
         capi.spgpuTuningReload()
-        capi.spgpuSetSpmvForm(handle, FORMS[form])
+        capi.spgpuSetSpmvForm(handle, 1 if form == "raggedg" else 0 if form.startswith("ragged") else 3 if form.startswith("tile") else FORMS[form])
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
             for _ in range(3):
@@ -94,22 +97,40 @@ if "uniform" in cases:
         h = synth.hell_uniform_on_device(n // 32 * 32, 32, pattern, letter, 32, seed=1)
         h["slots"] = h["nnz"]
         torch.cuda.synchronize()
-        run(h, f"uniform 32/row, columns {pattern}", ["gather", "strips", "tile0", "tile1", "tile2", "tile3"])
+        run(h, f"uniform 32/row, columns {pattern}", ["gather", "strips", "tile0", "tile2", "tile3"])
         del h
         torch.cuda.empty_cache()
 
+if "mild" in cases:
+    # rows of 24..40 entries near the row, ordered by length inside windows: the permutation and the scattered z writes of
+    # the ordered power-law case without its long rows
+    rng = np.random.default_rng(1)
+    lengths = rng.integers(24, 41, size=n).astype(np.int32)
+    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, "near", 2048, letter, seed=5)
+    torch.cuda.synchronize()
+    for name, order in [("plain", None)] + [(f"sorted window {w}", (w, 0)) for w in (1024, 2048, 4096)]:
+        h = formats.coo_to_ordered_hell_device(handle, n, rows_t, cols_t, vals_t, letter, 32, *(order or (0, 0)), order=order is not None)
+        run(h, f"24..40/row near, {name}", os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(","))
+        del h
+        torch.cuda.empty_cache()
+    del rows_t, cols_t, vals_t
+    torch.cuda.empty_cache()
+
 if "powerlaw" in cases:
     lengths = synth.power_law_lengths(n, mean=32.0, max_len=2048, seed=5)
-    for pattern in ("near", "random"):
+    for pattern in os.environ.get("EXP_PATTERNS", "near,random").split(","):
         rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 2048, letter, seed=5)
         torch.cuda.synchronize()
         orders = [("plain", None), ("sorted all", (0, 0))]
         if pattern == "near":
-            orders += [(f"sorted window {w} long>{t}", (w, t)) for w, t in ((4096, 0), (2048, 256), (4096, 256), (4096, 128), (8192, 256), (16384, 0))]
+            pairs = [tuple(int(v) for v in item.split(":")) for item in os.environ.get("EXP_ORDERS", "2048:128,2048:256,4096:256,8192:256,16384:0").split(",")]
+            orders += [(f"sorted window {w} long>{t}", (w, t)) for w, t in pairs]
+        if os.environ.get("EXP_ONLY_WINDOWED"):
+            orders = orders[2:]
         for name, order in orders:
             h = formats.coo_to_ordered_hell_device(handle, n, rows_t, cols_t, vals_t, letter, 32, *(order or (0, 0)),
                                                    order=order is not None)
-            forms = ["gather"] if (pattern == "random" or order is None or order == (0, 0)) else ["gather", "tile0", "tile1", "tile2"]
+            forms = ["gather"] if (pattern == "random" or order is None or order == (0, 0)) else os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(",")
             run(h, f"power-law {pattern}, {name}", forms)
             del h
             torch.cuda.empty_cache()
