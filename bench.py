@@ -40,6 +40,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg")
     p.add_argument("--workload", default="auto", choices=["auto", "spmv", "spmm"],
                    help="auto: spmv on 1 GPU (the headline metric), row-sharded spmm on more")
+    p.add_argument("--ell-rows", type=int, default=2_000_000, help="rows of the ELL side of configs[2] (ELL at 10 M rows is 164 GB)")
+    p.add_argument("--grid", type=int, default=512, help="grid edge of configs[3] (HDIA 7-point Laplacian grid^3)")
     p.add_argument("--spmm-rows-per-gpu", type=int, default=5_000_000)
     p.add_argument("--rhs", type=int, default=16)
     p.add_argument("--spmm-pattern", default="banded", choices=["banded", "random", "window"])
@@ -133,9 +135,13 @@ def usable_cores():
 
 
 def cpu_baseline(h, x, seconds):
-    """cpu_baseline leg: the oracle's HELL SpMV (orc_dhellspmv, OpenMP over rows; a PORT -- the
-    reference has no CPU SpMV) on the first rows of the same matrix, called straight through ctypes
-    on pre-converted arrays so that only the C loop is timed."""
+    """cpu_baseline leg, on a bounded sample of the same matrix:
+      SpMV        the oracle's orc_dhellspmv (C, OpenMP over rows; a PORT -- the reference has no CPU SpMV), on ALL the
+                  cores this job may use and on ONE core;
+      conversion  what the reference's CPU path really is: cooToEll -> ellToHell and cooToHdia on one thread
+                  (ell.c:39-80, hell.c:46-104, hdia.cpp:230-324).  Timed on the reference's own objects where they
+                  travelled with the tree (oracle/_ref, kind "reference"), else on the oracle's byte-identical restatement.
+    value/cores are the all-cores SpMV figure."""
     import numpy as np
     import oracle_api as O
     from spgpu_amd import synth
@@ -145,22 +151,258 @@ def cpu_baseline(h, x, seconds):
     zs = np.zeros(sample_rows)
     nnz = int(sub["row_lengths"].sum(dtype=np.int64))
     cores = usable_cores()
-    O.orc.orc_set_threads(cores)
     ptr = lambda a: C.c_void_p(a.ctypes.data)
     call = lambda: O.orc.orc_dhellspmv(ptr(zs), None, C.c_double(1.0), ptr(sub["values"]), ptr(sub["indices"]),
                                        sub["hack_size"], ptr(sub["hack_offsets"]), ptr(sub["row_lengths"]), None,
                                        sample_rows, ptr(xs), C.c_double(0.0), 0, 1)
-    call()  # warm the pages
-    t0, passes = time.perf_counter(), 0
-    while True:
-        call()
-        passes += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or passes >= 1000:
-            break
-    return dict(value=round(2.0 * nnz * passes / dt * 1e-9, 3), unit="GFLOP/s", cores=cores, kind="port",
+
+    def spmv_rate(threads, budget):
+        O.orc.orc_set_threads(threads)
+        call()  # warm the pages
+        t0, passes = time.perf_counter(), 0
+        while True:
+            call()
+            passes += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or passes >= 1000:
+                break
+        return round(2.0 * nnz * passes / dt * 1e-9, 3), passes, dt
+
+    all_rate, passes, dt = spmv_rate(cores, seconds * 0.35)
+    one_rate, passes1, dt1 = spmv_rate(1, seconds * 0.35)
+    O.orc.orc_set_threads(cores)
+
+    # conversion: COO of the first rows of the same matrix (row-major triplets rebuilt from the HELL sample)
+    conv_rows = min(sample_rows, 500_000)
+    hs, L = sub["hack_size"], int(sub["row_lengths"][0])
+    vals = sub["values"][:conv_rows * L].reshape(conv_rows // hs, L, hs).transpose(0, 2, 1).reshape(-1)
+    cols = sub["indices"][:conv_rows * L].reshape(conv_rows // hs, L, hs).transpose(0, 2, 1).reshape(-1)
+    rows = np.repeat(np.arange(conv_rows, dtype=np.int32), L)
+    vals, cols = np.ascontiguousarray(vals), np.ascontiguousarray(cols, np.int32)
+    conv = O.reference_converters() if O.reference_available() else None
+    kind = "reference" if conv is not None else "port"
+    conv = conv or O.oracle_converters
+    t0 = time.perf_counter()
+    ell = conv.coo_to_ell(conv_rows, rows, cols, vals)
+    hell = conv.ell_to_hell(ell, hs)
+    t_hell = time.perf_counter() - t0
+    assert hell["values"].tobytes() == sub["values"][:conv_rows * L].tobytes(), "converter output differs from the device-built matrix"
+    n_cols = int(xs.size)
+    t0 = time.perf_counter()
+    conv.coo_to_hdia(conv_rows, n_cols, rows, cols, vals, hs)
+    t_hdia = time.perf_counter() - t0
+    return dict(value=all_rate, unit="GFLOP/s", cores=cores, kind="port",
                 sample=f"oracle orc_dhellspmv (C, OpenMP, {cores} threads) on the first {sample_rows} rows "
-                       f"({nnz} nnz) of the same matrix, {passes} passes in {dt:.1f} s")
+                       f"({nnz} nnz) of the same matrix, {passes} passes in {dt:.1f} s",
+                all_cores=dict(gflops=all_rate, threads=cores), one_core=dict(gflops=one_rate, threads=1, passes=passes1, seconds=round(dt1, 2)),
+                convert_single_thread_s=dict(kind=kind, rows=conv_rows, nnz=int(rows.size),
+                                             coo_to_ell_to_hell=round(t_hell, 3), coo_to_hdia=round(t_hdia, 3),
+                                             nnz_per_s_hell=round(rows.size / t_hell), nnz_per_s_hdia=round(rows.size / t_hdia),
+                                             note="reference ell.c:39-80 + hell.c:46-104 and hdia.cpp:230-324, one thread, as the reference runs them"))
+
+
+def check_windows(h, x, z, letter, shape, windows=3, rows=2048):
+    """Parity at full size for ANY device HELL dict (ragged, ordered through rIdx or not): `windows` hack-aligned row
+    windows of the device result against the oracle run in the kernel's summation order (`shape`: the spmv_tail
+    parameters, tests/oracle_api.py slab_shape), bit for bit."""
+    import torch
+    import oracle_api as O
+    from spgpu_amd import synth
+    xs = x.cpu().numpy()
+    step = max(1, (h["rows"] - rows) // max(windows - 1, 1))
+    for w in range(windows):
+        first = min(w * step, h["rows"] - rows) // 2048 * 2048
+        sub = synth.hell_rows_to_host_general(h, first, rows)
+        want = O.spmv_tail(sub, xs, None, 1.0, 0.0, **shape)
+        if h.get("rIdx") is not None:
+            got = z[h["rIdx"][first:first + rows].to(torch.int64)].cpu().numpy()
+        else:
+            got = z[first:first + rows].cpu().numpy()
+        if got.tobytes() != want.tobytes():
+            return f"MISMATCH in ordered rows [{first},{first + rows})"
+    return f"bit-exact vs oracle on {windows} x {rows} rows"
+
+
+def bench_powerlaw(args, handle, stream, dev, rows):
+    """The north_star target: HELL fp64 on power-law row lengths (mean 32, max 2048), as the rows come and after the
+    device-side ordering by length (spgpuOellOrderDevice: windows of 4096 rows, rows longer than 256 set aside; the
+    COO route through spgpuCooToHellDevice), columns near the row (+-2048, not consecutive) and scattered."""
+    import torch
+    import oracle_api as O
+    from spgpu_amd import capi, formats, synth
+    letter, elem = "D", 8
+    lengths = synth.power_law_lengths(rows, mean=32.0, max_len=2048, seed=5)
+    x = synth.device_vector(rows, letter, 3, dev)
+    z = torch.zeros(rows, dtype=torch.float64, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    out = dict(rows=rows, mean_len=round(float(lengths.mean()), 2), max_len=int(lengths.max()),
+               order="spgpuOellOrderDevice(window=4096, longRows=256) + spgpuCooPermuteRowsDevice + spgpuCooToHellDevice")
+    for pattern in ("near", "random"):
+        coo = synth.ragged_coo_on_device(lengths, rows, pattern, 2048, letter, seed=5, device=dev)
+        torch.cuda.synchronize()
+        for name, ordered in (("plain", False), ("sorted", True)):
+            t0 = time.perf_counter()
+            h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, 4096, 256, order=ordered)
+            build_s = time.perf_counter() - t0
+            # scattered columns: the LDS tile cannot help, the caller says so (include/spgpu/tuning.h)
+            capi.spgpuSetSpmvForm(handle, capi.FORM_GATHER if (ordered and pattern == "random") else capi.FORM_AUTO)
+            call = lambda: capi.hellspmv[letter](handle, p(z), None, C.c_double(1.0), p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]),
+                                                 p(h["rS"]), p(h["rIdx"]), 32, rows, p(x), C.c_double(0.0), 0)
+            time_launches(stream, call, 3)
+            t = time_launches(stream, call, 20) / 20
+            z.zero_()
+            torch.cuda.synchronize()
+            time_launches(stream, call, 1)
+            capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
+            hacks = (rows + 31) // 32
+            alg = h["nnz"] * (elem + 4) + rows * (4 + elem) + rows * elem + hacks * 4 + (rows * 4 if ordered else 0)
+            shape = O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP) if ordered else O.slab_shape(letter)
+            out[f"{pattern}_{name}"] = dict(slots_per_nnz=round(h["slots"] / h["nnz"], 3), ms=round(t * 1e3, 4),
+                                            gflops=round(2.0 * h["nnz"] / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
+                                            frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), algorithmic_bytes=alg,
+                                            hell_GB=round(h["slots"] * (elem + 4) * 1e-9, 2), build_ms=round(build_s * 1e3, 1),
+                                            parity=check_windows(h, x, z, letter, shape))
+            del h
+            torch.cuda.empty_cache()
+        del coo
+        torch.cuda.empty_cache()
+    return out
+
+
+def bench_c1(handle, stream, dev):
+    """BASELINE configs[0]: spgpuDhellspmv on the 5-point Laplacian 1024 x 1024, built by the HOST converters exactly as
+    the reference's harness does (hellPerf.cpp:127-264); converter output checked against the checksums the reference's
+    own objects produced (tests/golden/checksums.json), the product against the oracle on ALL rows; and the CG solver of
+    tools/cg_amd.c (plain C on the ABI) for the time per iteration of a captured iteration."""
+    import subprocess
+    import numpy as np
+    import torch
+    import oracle_api as O
+    from spgpu_amd import capi, formats, synth
+    n, m, r, c, v = synth.laplacian_2d_5pt(1024)
+    hell = formats.ell_to_hell(formats.coo_to_ell(n, r, c, v), 32)
+    with open(os.path.join(ROOT, "tests", "golden", "checksums.json")) as f:
+        want = json.load(f)["lap2d_1024_d"]["fnv"]
+    converters = all(O.fnv(hell[k]) == want[w] for k, w in (("values", "hell_values"), ("indices", "hell_indices"),
+                                                            ("hack_offsets", "hell_hack_offsets"), ("row_lengths", "row_lengths")))
+    x = synth.hashed_vector(m)
+    dx, dz = formats.to_device(x, dev), torch.empty(n, dtype=torch.float64, device=dev)
+    mat = formats.DeviceHell(hell, dev)
+    torch.cuda.synchronize()
+    call = lambda: mat.spmv(handle, dz, None, 1.0, dx, 0.0, avg_nnz=5)
+    time_launches(stream, call, 20)
+    t = time_launches(stream, call, 200) / 200
+    torch.cuda.synchronize()
+    ok = dz.cpu().numpy().tobytes() == O.default_spmv(hell, x, None, 1.0, 0.0).tobytes()
+    alg = hell_algorithmic_bytes(mat.nnz, n, m, n // 32)
+    out = dict(workload="spgpuDhellspmv, 5-point Laplacian 1024 x 1024 (1 048 576 rows, 5 238 784 nnz), host-converted",
+               us=round(t * 1e6, 2), gflops=round(2.0 * mat.nnz / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
+               frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), algorithmic_bytes=alg,
+               converters="byte-identical to the reference build (checksums)" if converters else "MISMATCH",
+               parity="bit-exact vs oracle on all rows" if ok else "MISMATCH")
+    cg = os.path.join(ROOT, "tools", "cg_amd.bin")
+    if os.path.exists(cg):
+        try:
+            run = subprocess.run([cg, "1024", "60", "1e-30"], capture_output=True, text=True, timeout=120)
+            for line in run.stdout.splitlines():
+                if line.startswith("graph replay:"):
+                    words = line.replace("(", " ").replace(")", " ").replace(";", " ").split()
+                    out["cg_graph_us_per_iteration"] = float(words[words.index("us") - 1])
+                    out["cg_eager_host_scalars_us_per_iteration"] = float(words[words.index("scalars:") + 1])
+                    out["cg_iterates"] = line.split("; iterate")[-1].strip()
+        except (OSError, subprocess.SubprocessError, ValueError) as error:
+            out["cg"] = f"not run: {error!r}"
+    return out
+
+
+def bench_c3(handle, stream, dev, rows, ell_rows):
+    """BASELINE configs[2]: HELL fp32 vs ELL fp32 on power-law row lengths (max 2048, mean 32), random columns: time and
+    FOOTPRINT (the memory win of HELL).  ELL at 10 M rows needs 164 GB: measured at `ell_rows` rows beside HELL on the
+    same rows; HELL also at the full size."""
+    import torch
+    import oracle_api as O
+    from spgpu_amd import capi, synth
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    n = rows // 32 * 32
+    lengths = synth.power_law_lengths(n, mean=32.0, max_len=2048, seed=5)
+    out = {}
+
+    def hell_case(count):
+        h = synth.hell_ragged_on_device(lengths[:count], count, "S", 32, seed=5, device=dev)
+        h["letter"] = "S"
+        x, z = synth.device_vector(count, "S", 3, dev), torch.zeros(count, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        call = lambda: capi.hellspmv["S"](handle, p(z), None, 1.0, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
+                                          None, 32, count, p(x), 0.0, 0)
+        time_launches(stream, call, 3)
+        t = time_launches(stream, call, 20) / 20
+        torch.cuda.synchronize()
+        alg = h["nnz"] * 8 + count * 8 + count * 4 + (count // 32) * 4
+        return dict(rows=count, nnz=h["nnz"], ms=round(t * 1e3, 4), gflops=round(2.0 * h["nnz"] / t * 1e-9, 1),
+                    hbm_gbs=round(alg / t * 1e-9, 1), frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4),
+                    footprint_GB=round((h["slots"] * 8 + count * 4 + count // 32 * 4) * 1e-9, 2),
+                    slots_per_nnz=round(h["slots"] / h["nnz"], 3), parity=check_windows(h, x, z, "S", O.slab_shape("S")))
+
+    out["hell_fp32"] = hell_case(n)
+    torch.cuda.empty_cache()
+    ne = min(ell_rows, n) // 32 * 32
+    out["hell_fp32_same_rows_as_ell"] = hell_case(ne)
+    torch.cuda.empty_cache()
+    e = synth.ell_ragged_on_device(lengths[:ne], ne, "S", seed=6, device=dev)
+    x, z = synth.device_vector(ne, "S", 3, dev), torch.zeros(ne, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    call = lambda: capi.ellspmv["S"](handle, p(z), None, 1.0, p(e["cM"]), p(e["rP"]), e["pitch"], e["pitch"], p(e["rS"]),
+                                     None, 32, e["max_row"], ne, p(x), 0.0, 0)
+    time_launches(stream, call, 3)
+    t = time_launches(stream, call, 20) / 20
+    alg = e["nnz"] * 8 + ne * 8 + ne * 4
+    out["ell_fp32"] = dict(rows=ne, nnz=e["nnz"], ms=round(t * 1e3, 4), gflops=round(2.0 * e["nnz"] / t * 1e-9, 1),
+                           hbm_gbs=round(alg / t * 1e-9, 1), frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4),
+                           footprint_GB=round((e["pitch"] * e["max_row"] * 8 + ne * 4) * 1e-9, 2))
+    out["ell_footprint_GB_at_full_rows"] = round(((n + 31) // 32 * 32) * int(lengths.max()) * 8e-9 + n * 4e-9, 1)
+    return out
+
+
+def bench_c4(handle, stream, dev, grid):
+    """BASELINE configs[3]: HDIA fp64, 7-point Laplacian grid^3 (512^3: 134 M rows, 938 M nnz), oracle check on a
+    2048-row window in the middle of the grid."""
+    import numpy as np
+    import torch
+    import oracle_api as O
+    from spgpu_amd import capi, synth
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    m = grid
+    d = synth.hdia_laplacian7_on_device(m, "D", 32, device=dev)
+    n = d["rows"]
+    hacks = n // 32
+    x, y = synth.device_vector(n, "D", 3, dev), synth.device_vector(n, "D", 4, dev)
+    z = torch.empty_like(y)
+    torch.cuda.synchronize()
+    out = dict(rows=n, nnz=d["nnz"], stored_diagonals=d["height"])
+    for beta in (0.0, 0.5):
+        call = lambda: capi.hdiaspmv["D"](handle, p(z), p(y), 1.0, p(d["dM"]), p(d["offsets"]), 32, p(d["hack_offsets"]), n, n, p(x), beta)
+        time_launches(stream, call, 3)
+        t = time_launches(stream, call, 20) / 20
+        torch.cuda.synchronize()
+        slots = 32 * d["height"]
+        alg = slots * 8 + d["height"] * 4 + (hacks + 1) * 4 + n * 8 + n * 8 * (2 if beta else 1)
+        first = (hacks // 2) * 32
+        ho = d["hack_offsets"][hacks // 2: hacks // 2 + 65].cpu().numpy().astype(np.int64)
+        # the oracle indexes x by offsets[d] + local row: hand it the slice of x the window can reach, shifted by m^2
+        xs = x[max(first - m * m, 0): min(first + 2048 + m * m, n)].cpu().numpy()
+        xw = np.zeros(2048 + 2 * m * m)
+        lead = max(first - m * m, 0) - (first - m * m)
+        xw[lead:lead + xs.size] = xs
+        sub = dict(letter="D", rows=2048, cols=xw.size, hack_size=32, hack_offsets=(ho - ho[0]).astype(np.int32),
+                   offsets=(d["offsets"][ho[0]:ho[-1]].cpu().numpy().astype(np.int64) + m * m).astype(np.int32),
+                   values=d["dM"][ho[0] * 32: ho[-1] * 32].cpu().numpy())
+        ys = y[first:first + 2048].cpu().numpy()
+        want = O.hdia_spmv(sub, xw, ys if beta else None, 1.0, beta)
+        ok = z[first:first + 2048].cpu().numpy().tobytes() == want.tobytes()
+        out[f"beta{beta:g}"] = dict(ms=round(t * 1e3, 4), gflops=round(2.0 * d["nnz"] / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
+                                    frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), algorithmic_bytes=alg,
+                                    parity="bit-exact vs oracle on 2048 rows" if ok else "MISMATCH")
+    return out
 
 
 def run_spmv(args, rank, world):
@@ -279,10 +521,23 @@ def run_spmv(args, rank, world):
                                      parity=spot_check_hell(h, xt, yt, zt, 1.0, 0.0))
                 del xt, yt, zt
             out["other_types_banded"] = types
+            # the other BASELINE configurations and the north_star target, each with its oracle check
+            del h, step, s2
+            torch.cuda.empty_cache()
+            h = step = s2 = None
+            configs = {}
+            for name, fn in (("powerlaw_fp64", lambda: bench_powerlaw(args, handle, stream, dev, args.rows)),
+                             ("c1_laplacian_1024", lambda: bench_c1(handle, stream, dev)),
+                             ("c3_hell_vs_ell_fp32", lambda: bench_c3(handle, stream, dev, args.rows, args.ell_rows)),
+                             ("c4_hdia_7pt", lambda: bench_c4(handle, stream, dev, args.grid))):
+                try:
+                    configs[name] = fn()
+                except Exception as error:  # noqa: BLE001 - an extra must not take the headline record down
+                    configs[name] = dict(error=repr(error))
+                torch.cuda.empty_cache()
+            out["configs"] = configs
             if world == 1:
                 # the N = 1 point of the curve `--gpus N` (N > 1) measures: same sharded SpMM step on one rank
-                del h, step, s2
-                torch.cuda.empty_cache()
                 one = measure_spmm(args, 0, 1, handle, stream, dev, 50, 5)
                 out["spmm_1gpu"] = dict(value=one["value"], unit=one["unit"], ms_per_step=one["ms_per_step"],
                                         workload=one["config"]["workload"], roofline_frac=one["roofline"]["frac"],

@@ -228,7 +228,7 @@ void spgpuTuningReload(void)
     t.xTile = envInt("SPGPU_X_TILE", -1);
     t.xTileShape = envInt("SPGPU_X_TILE_SHAPE", 0);
     t.deepSplit = envInt("SPGPU_DEEP_SPLIT", -1);
-    t.deepCap = envInt("SPGPU_DEEP_CAP", 128);
+    t.deepCap = envInt("SPGPU_DEEP_CAP", 256);
     t.ragged = envInt("SPGPU_RAGGED", 1);
     t.raggedShape = envInt("SPGPU_RAGGED_SHAPE", 0);
     t.l1Nt = envInt("SPGPU_L1_NT", -1);

@@ -76,6 +76,7 @@ template <typename T> struct SlabArgs {
     int* deepCounts;             /* [SPGPU_DEEP_QUEUES] entries registered per queue (may exceed the queue's capacity) */
     SpgpuDeepEntry* deepEntries; /* [SPGPU_DEEP_QUEUES][SPGPU_DEEP_QUEUE_ENTRIES] */
     T* deepPartials;             /* [..][..][32] row sums over the columns < deepCap */
+    int xcdRun;                  /* raggedSpmvKernel: row blocks per XCD run (0: hardware order) */
 };
 
 constexpr int kBlockThreads = 256;
@@ -922,7 +923,8 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
      * one does to a ragged matrix, and then whole hacks are deep -- or when SPGPU_DEEP_SPLIT says so. */
     bool deepSplit = (tune->deepSplit >= 0 ? tune->deepSplit != 0 : a.rIdx != nullptr) && wideOk &&
                      (variant == 21 || variant == 22);
-    a.deepCap = tune->deepCap > 0 ? tune->deepCap : 128;
+    a.deepCap = tune->deepCap > 0 ? tune->deepCap : 256;
+    a.xcdRun = tune->xcdOrder;
     a.deepCounts = nullptr;
     a.deepEntries = nullptr;
     a.deepPartials = nullptr;

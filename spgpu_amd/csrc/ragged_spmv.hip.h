@@ -47,7 +47,11 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int sub = lane % LPC, phase = lane / LPC;
-    const long long blockRow0 = (long long)blockIdx.x * ROWS;
+    /* Consecutive workgroups (in row order) read overlapping slices of x.  The hardware deals workgroup ids round-robin
+     * over the 8 XCDs, each with an L2 of its own: left alone, every slice is fetched from memory by all eight.  With
+     * a.xcdRun > 0 the id is permuted so that runs of xcdRun consecutive row blocks share an XCD (speed only). */
+    const unsigned logicalBlock = a.xcdRun > 0 ? xcdRuns(blockIdx.x, gridDim.x, (unsigned)a.xcdRun) : blockIdx.x;
+    const long long blockRow0 = (long long)logicalBlock * ROWS;
     const T* __restrict__ x = a.x;
 
     /* ---- 1: row lengths and strip bases of the whole workgroup --------------------------------------------------- */
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
 }
 
 #ifndef SPGPU_RAGGED_UNROLL
-#define SPGPU_RAGGED_UNROLL(RPL) 2 /* wave-wide loads per stage (each PH slab columns) */
+#define SPGPU_RAGGED_UNROLL(RPL) ((RPL) >= 4 ? 2 : 4) /* wave-wide loads per stage: 16 slab columns for 4- and 8-byte elements */
 #endif
 /* Shapes (SPGPU_RAGGED_SHAPE; 0 is the default): workgroup lanes / tile / sub-groups per workgroup. */
 template <typename T, int RPL, bool IS_HELL, bool DEEP>

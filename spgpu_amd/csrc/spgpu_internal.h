@@ -79,7 +79,7 @@ typedef struct SpgpuTuning {
     int xTile;       /* -1: by the handle's hint */
     int xTileShape;  /* 0 */
     int deepSplit;   /* -1: when rIdx is given */
-    int deepCap;     /* 128 */
+    int deepCap;     /* 256 */
     int ragged;      /* 1: the queue-driven kernel where the deep split is on */
     int raggedShape; /* 0 */
     int l1Nt;        /* -1: by size */

@@ -422,7 +422,7 @@ for _L, _T in SCALAR.items():
     _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32, i32,
                    i32, i32, i32]
 
-DEEP_CAP = 128   # SPGPU_DEEP_CAP default
+DEEP_CAP = 256   # SPGPU_DEEP_CAP default
 # deepSpmvKernel (csrc/ellpack_spmv.hip launchDeep): phases = 64 / (32 / rows per lane); chunks of 128 columns
 DEEP_SHAPE = {"S": dict(deep_phases=8, deep_chunk=128), "D": dict(deep_phases=4, deep_chunk=128),
               "C": dict(deep_phases=4, deep_chunk=128), "Z": dict(deep_phases=2, deep_chunk=128)}
@@ -453,7 +453,7 @@ def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0):
     deep = dict(deep_cap=deep_cap, **DEEP_SHAPE[letter]) if deep_cap > 0 else {}
     if form == "ragged":   # raggedSpmvKernel: one wavefront per 32-row sub-group, 64 / (32 / rpl) phases, no tail rows
         phases = 2 * rpl
-        return dict(group_rows=32, rows_per_lane=rpl, step=phases * 2, tail_lanes=0, phases=phases, **deep)
+        return dict(group_rows=32, rows_per_lane=rpl, step=phases * (2 if rpl >= 4 else 4), tail_lanes=0, phases=phases, **deep)
     if form == "xtile":
         if tile_shape == 1 and not deep:
             return dict(group_rows=32, rows_per_lane=rpl, step=4 * rpl, tail_lanes=16, phases=2 * rpl) if rpl > 1 else None

@@ -30,7 +30,7 @@ x = synth.device_vector(n, letter, 3)
 z = torch.zeros(n, dtype=x.dtype, device="cuda:0")
 xs = x.cpu().numpy()
 FORMS = {"auto": 0, "gather": 1, "strips": 2, "tile0": 3, "tile1": 3, "tile2": 3, "tile3": 3}
-DEEP_CAP = int(os.environ.get("SPGPU_DEEP_CAP", "128"))
+DEEP_CAP = int(os.environ.get("SPGPU_DEEP_CAP", "256"))
 
 
 def shape_of(form, ordered):
@@ -93,11 +93,11 @@ def run(h, label, forms):
 
 
 if "uniform" in cases:
-    for pattern in ("near2048", "near512", "window", "banded"):
+    for pattern in os.environ.get("EXP_PATTERNS", "near2048,near512,window,banded").split(","):
         h = synth.hell_uniform_on_device(n // 32 * 32, 32, pattern, letter, 32, seed=1)
         h["slots"] = h["nnz"]
         torch.cuda.synchronize()
-        run(h, f"uniform 32/row, columns {pattern}", ["gather", "strips", "tile0", "tile2", "tile3"])
+        run(h, f"uniform 32/row, columns {pattern}", os.environ.get("EXP_FORMS", "gather,strips,tile0,tile2,tile3,tile4,tile5").split(","))
         del h
         torch.cuda.empty_cache()
 
