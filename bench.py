@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--exchange", default="needed", choices=["needed", "allgather"],
                    help="spmm on N>1 ranks: move only the X rows the off-block columns name (one all_to_all per step), or "
                         "all-gather the whole of X; with 'needed' the all-gather step is timed as well and reported beside it")
+    p.add_argument("--driver", default="c", choices=["c", "torch"],
+                   help="spmm: who issues a step -- libspgpu.so's sharded driver (RCCL through dlopen), or torch.distributed")
     p.add_argument("--no-split", action="store_true",
                    help="spmm: do not cut the local block by column ownership (no compute/all-gather overlap)")
     return p.parse_args()
@@ -596,31 +598,128 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
 
     new_rows = lambda rows: torch.empty(rows, k, dtype=torch.float64, device=dev)
     needed_mode = split and args.exchange == "needed"
-    if needed_mode:
-        # only the X rows A_rest names travel: its columns are renumbered into that sorted list.  The local part of
-        # the set-up runs first and all ranks agree that it worked before any of them enters the set-up collectives
-        # (otherwise: everyone falls back to the all-gather).
-        try:
-            needed, compact = sharded.needed_rows_of(rest["rP"], 0)
-            rest_compact = dict(rest, rP=compact.contiguous())
-            ready = 1.0
-        except Exception as error:  # noqa: BLE001 - any local failure means "use the other exchange"
-            print(f"rank {rank}: needed-rows set-up failed ({error!r}); falling back to all-gather", file=sys.stderr, flush=True)
-            ready = 0.0
-        if world > 1 or (dist.is_available() and dist.is_initialized()):
-            flag = torch.tensor([ready], device=dev, dtype=torch.float64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ready = float(flag.item())
-        needed_mode = ready > 0.5
-    if needed_mode:
-        op = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest_compact, local_product, new_rows, needed=needed)
-        op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows)
-    else:
-        op = op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows)
-    torch.cuda.synchronize()
+    distributed = world > 1 or (dist.is_available() and dist.is_initialized())
 
-    def step():
-        op.step(z_local, y_local, 1.0, x_local, 0.0)
+    # ---- the driver of a step: the C ABI (include/spgpu/sharded.h: packing kernel, RCCL and both products issued by the
+    # library) unless --driver torch or the gloo rehearsal (two ranks on one GPU cannot share an RCCL communicator)
+    driver = "torch" if (rehearsing() or args.driver == "torch") else "c"
+    plans, comm = {}, None
+    if driver == "c":
+        ok = 1.0
+        try:
+            if distributed:
+                ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    raw = (C.c_char * 128)()
+                    if capi.spgpuCommGetUniqueId(raw) != capi.SPGPU_SUCCESS:
+                        raise RuntimeError("spgpuCommGetUniqueId failed")
+                    ident.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+                dist.broadcast(ident, 0)
+                torch.cuda.synchronize()
+                raw = (C.c_char * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
+                comm = C.c_void_p()
+                if capi.spgpuCommInitRank(C.byref(comm), world, raw, rank) != capi.SPGPU_SUCCESS:
+                    raise RuntimeError("spgpuCommInitRank failed")
+            first_rows = (C.c_longlong * (world + 1))(*[r * rows_local for r in range(world + 1)])
+            own_block = capi.hell_block(own, L)
+            rest_block = capi.hell_block(rest, L) if rest is not None else None
+            kinds = [("allgather", capi.EXCHANGE_ALLGATHER)] + ([("needed", capi.EXCHANGE_NEEDED)] if needed_mode else [])
+            for name, kind in kinds:
+                plan = capi.ShardedPlan()
+                status = capi.spgpuDhellspmmShardedCreate(C.byref(plan), handle, comm, rank, world, first_rows, C.byref(own_block),
+                                                          C.byref(rest_block) if rest_block is not None else None, k, kind)
+                if status != capi.SPGPU_SUCCESS:
+                    raise RuntimeError(f"spgpuDhellspmmShardedCreate({name}) returned {status}")
+                plans[name] = plan
+        except Exception as error:  # noqa: BLE001 - any failure of the set-up: every rank falls back together
+            print(f"rank {rank}: C driver set-up failed ({error!r}); falling back to the torch.distributed driver", file=sys.stderr, flush=True)
+            ok = 0.0
+        if distributed:
+            flag = torch.tensor([ok], device=dev, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = float(flag.item())
+        if ok < 0.5:
+            for plan in plans.values():
+                capi.spgpuDhellspmmShardedDestroy(plan)
+            plans, driver = {}, "torch"
+
+    if driver == "c":
+        plan_step = plans["needed" if needed_mode else "allgather"]
+        one, zero = C.c_double(1.0), C.c_double(0.0)
+
+        def step():
+            capi.spgpuDhellspmmShardedStep(plan_step, p(z_local), p(y_local), one, p(x_local), zero)
+
+        def step_allgather():
+            capi.spgpuDhellspmmShardedStep(plans["allgather"], p(z_local), p(y_local), one, p(x_local), zero)
+
+        def products_only():
+            capi.spgpuDhellspmmShardedProducts(plan_step, p(z_local), p(y_local), one, p(x_local), zero)
+
+        def gather_only():
+            capi.spgpuDhellspmmShardedExchange(plans["allgather"], p(x_local))
+            capi.spgpuDhellspmmShardedExchangeWait(plans["allgather"])
+
+        def needed_only():
+            capi.spgpuDhellspmmShardedExchange(plan_step, p(x_local))
+            capi.spgpuDhellspmmShardedExchangeWait(plan_step)
+
+        rows_received = lambda: int(capi.spgpuDhellspmmShardedRowsReceived(plan_step))
+    else:
+        if needed_mode:
+            # only the X rows A_rest names travel: its columns are renumbered into that sorted list.  The local part of
+            # the set-up runs first and all ranks agree that it worked before any of them enters the set-up collectives
+            # (otherwise: everyone falls back to the all-gather).
+            try:
+                needed, compact = sharded.needed_rows_of(rest["rP"], 0)
+                rest_compact = dict(rest, rP=compact.contiguous())
+                ready = 1.0
+            except Exception as error:  # noqa: BLE001 - any local failure means "use the other exchange"
+                print(f"rank {rank}: needed-rows set-up failed ({error!r}); falling back to all-gather", file=sys.stderr, flush=True)
+                ready = 0.0
+            if distributed:
+                flag = torch.tensor([ready], device=dev, dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ready = float(flag.item())
+            needed_mode = ready > 0.5
+        products_stream = stream.cuda_stream
+        if needed_mode:
+            op = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest_compact, local_product, new_rows, needed=needed,
+                                     products_stream=products_stream)
+            op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows,
+                                               products_stream=products_stream)
+        else:
+            op = op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows,
+                                                    products_stream=products_stream)
+
+        def step():
+            op.step(z_local, y_local, 1.0, x_local, 0.0)
+
+        def step_allgather():
+            op_allgather.step(z_local, y_local, 1.0, x_local, 0.0)
+
+        def products_only():
+            if rest is None:
+                local_product(own, z_local, y_local, 1.0, op.x_full, 0.0)
+            else:
+                local_product(own, z_local, y_local, 1.0, x_local, 0.0)
+                if needed_mode:
+                    local_product(rest_compact, z_local, z_local, 1.0, op.needed.x_needed, 1.0)
+                else:
+                    local_product(rest, z_local, z_local, 1.0, op.x_full, 1.0)
+
+        def gather_only():
+            w = op_allgather.gather_x(x_local, async_op=False)
+            if w is not None:
+                w.wait()
+
+        def needed_only():
+            w = op.needed.start(x_local, async_op=False)
+            if w is not None:
+                w.wait()
+
+        rows_received = lambda: (sum(op.needed.recv_splits) - op.needed.recv_splits[rank]) if needed_mode else (world - 1) * rows_local
+    torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
         for _ in range(warmup):
@@ -640,7 +739,7 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
-    # untimed: the local product alone (X already gathered) and the all-gather alone
+    # untimed: the local products alone (on whatever the exchange buffer holds) and the exchanges alone
     def timed(fn, reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
@@ -650,46 +749,30 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                 fn()
             b.record(stream)
         b.synchronize()
+        torch.cuda.synchronize()
         return a.elapsed_time(b) / reps * 1e-3
 
-    def products_only():
-        if rest is None:
-            local_product(own, z_local, y_local, 1.0, op.x_full, 0.0)
-        else:
-            local_product(own, z_local, y_local, 1.0, x_local, 0.0)
-            if needed_mode:
-                local_product(rest_compact, z_local, z_local, 1.0, op.needed.x_needed, 1.0)
-            else:
-                local_product(rest, z_local, z_local, 1.0, op.x_full, 1.0)
-
-    def gather_only():
-        w = op_allgather.gather_x(x_local, async_op=False)
-        if w is not None:
-            w.wait()
-
-    def needed_only():
-        w = op.needed.start(x_local, async_op=False)
-        if w is not None:
-            w.wait()
-
-    distributed = world > 1 or (dist.is_available() and dist.is_initialized())
     t_compute = timed(products_only, 10)
-    t_gather = timed(gather_only, 10) if distributed else 0.0
+    t_gather = timed(gather_only, 10) if distributed and (split or world > 1) else 0.0
     t_needed = timed(needed_only, 10) if needed_mode and distributed else 0.0
     # the all-gather step beside the needed-rows step (same products, whole X moved)
     t_step_allgather = 0.0
     if needed_mode and distributed:
-        t_step_allgather = timed(lambda: op_allgather.step(z_local, y_local, 1.0, x_local, 0.0), max(3, steps // 10))
+        t_step_allgather = timed(step_allgather, max(3, steps // 10))
         if world > 1:
+            torch.cuda.synchronize()
             t = torch.tensor([t_step_allgather], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_step_allgather = float(t.item())
-    # X as a whole for the parity check below (every rank takes part in the collective), then the step under test last
-    gather_only()
+    # the step under test last, for the parity check below
     with torch.cuda.stream(stream):
         step()
     torch.cuda.synchronize()
-    x_everywhere = op_allgather.x_full
+    received = rows_received() if needed_mode else None
+    for plan in plans.values():
+        capi.spgpuDhellspmmShardedDestroy(plan)
+    if comm is not None:
+        capi.spgpuCommDestroy(comm)
     nnz_local = rows_local * L
     hacks = rows_local // 32
     alg = hell_algorithmic_bytes(nnz_local, rows_local, n_total, hacks, rhs=k)
@@ -702,9 +785,12 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
         import oracle_api as O
         whole = synth.hell_uniform_on_device(rows_local, L, args.spmm_pattern, "D", 32, seed=11 + rank, device=dev,
                                              n_cols=n_total, row_offset=first) if split else own
+        # X of every rank, regenerated here from the ranks' seeds (the check must not depend on the exchange under test)
+        x_everywhere = torch.cat([synth.device_vector(rows_local * k, "D", 21 + r, dev).view(rows_local, k) for r in range(world)])
         torch.cuda.synchronize()
         sub = synth.hell_rows_to_host(whole, 0, 1024)
         want = O.hell_spmm(sub, x_everywhere.cpu().numpy(), None, 1.0, 0.0)
+        del x_everywhere
         got = z_local[:1024].cpu().numpy()
         if split:
             ok = np.max(np.abs(got - want) / (np.abs(want) + 1.0)) <= 1e-12
@@ -733,10 +819,12 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                       compute_only_gflops_total=round(flops_total / t_compute * 1e-9, 1),
                       allgather_GBps_per_rank=round((world - 1) * rows_local * k * 8 / t_gather * 1e-9, 1) if t_gather else None,
                       needed_rows_only_ms=round(t_needed * 1e3, 4) if needed_mode else None,
-                      needed_rows_received_per_rank=(sum(op.needed.recv_splits) - op.needed.recv_splits[rank]) if needed_mode else None,
+                      needed_rows_received_per_rank=received, driver=driver,
                       allgather_step_ms=round(t_step_allgather * 1e3, 4) if t_step_allgather else None,
                       allgather_step_gflops_total=round(flops_total / t_step_allgather * 1e-9, 1) if t_step_allgather else None),
             parity=parity, cpu_baseline=None)
+        out["config"]["driver"] = ("C ABI (spgpuDhellspmmShardedStep: packing kernel, RCCL and products issued by libspgpu.so)" if driver == "c"
+                                   else "torch.distributed collectives + C-ABI products")
         if t_step_allgather:
             # BASELINE configs[4] word for word (all-gather of the dense X), measured in this same process
             out["as_named_allgather"] = dict(value=round(flops_total / t_step_allgather * 1e-9, 2), unit="GFLOP/s",

@@ -191,6 +191,40 @@ spgpuEllToOellDevice = _decl("spgpuEllToOellDevice", i32, [Handle, ptr, ptr, ptr
 spgpuCooPermuteRowsDevice = _decl("spgpuCooPermuteRowsDevice", i32, [Handle, ptr, ptr, i32, ptr, i32, i32, ptr])
 
 
+# ---- sharded.h (new: the row-sharded SpMM driver in C, RCCL through dlopen) ----------------------------------------
+class HellBlockD(C.Structure):
+    """spgpuHellBlockD: one HELL row block in device memory."""
+    _fields_ = [("cM", C.c_void_p), ("rP", C.c_void_p), ("hackSize", C.c_int), ("hackOffsets", C.c_void_p), ("rS", C.c_void_p),
+                ("rows", C.c_int), ("avgNnzPerRow", C.c_int), ("baseIndex", C.c_int), ("slots", C.c_longlong)]
+
+
+EXCHANGE_ALLGATHER, EXCHANGE_NEEDED = 0, 1
+ShardedPlan = C.c_void_p
+spgpuCommAvailable = _decl("spgpuCommAvailable", i32, [])
+spgpuCommGetUniqueId = _decl("spgpuCommGetUniqueId", i32, [ptr])
+spgpuCommInitRank = _decl("spgpuCommInitRank", i32, [C.POINTER(C.c_void_p), i32, ptr, i32])
+spgpuCommInitAll = _decl("spgpuCommInitAll", i32, [C.POINTER(C.c_void_p), i32, ptr])
+spgpuCommDestroy = _decl("spgpuCommDestroy", None, [ptr])
+spgpuDhellspmmShardedCreate = _decl("spgpuDhellspmmShardedCreate", i32,
+                                    [C.POINTER(ShardedPlan), Handle, ptr, i32, i32, C.POINTER(C.c_longlong), C.POINTER(HellBlockD),
+                                     C.POINTER(HellBlockD), i32, i32])
+spgpuDhellspmmShardedStep = _decl("spgpuDhellspmmShardedStep", i32, [ShardedPlan, ptr, ptr, C.c_double, ptr, C.c_double])
+spgpuDhellspmmShardedExchange = _decl("spgpuDhellspmmShardedExchange", i32, [ShardedPlan, ptr])
+spgpuDhellspmmShardedExchangeWait = _decl("spgpuDhellspmmShardedExchangeWait", i32, [ShardedPlan])
+spgpuDhellspmmShardedProducts = _decl("spgpuDhellspmmShardedProducts", i32, [ShardedPlan, ptr, ptr, C.c_double, ptr, C.c_double])
+spgpuDhellspmmShardedRowsReceived = _decl("spgpuDhellspmmShardedRowsReceived", C.c_longlong, [ShardedPlan])
+spgpuDhellspmmShardedExchanged = _decl("spgpuDhellspmmShardedExchanged", C.c_void_p, [ShardedPlan, C.POINTER(C.c_longlong)])
+spgpuDhellspmmShardedDestroy = _decl("spgpuDhellspmmShardedDestroy", None, [ShardedPlan])
+
+
+def hell_block(part, avg_nnz=0):
+    """A device HELL dict (cM, rP, hack_offsets, rS tensors; rows, hack_size) as the C struct; keep `part` alive."""
+    p = lambda t: t.data_ptr()
+    slots = int(part["slots"]) if "slots" in part else int(part["cM"].numel())
+    return HellBlockD(p(part["cM"]), p(part["rP"]), part["hack_size"], p(part["hack_offsets"]), p(part["rS"]), part["rows"], avg_nnz,
+                      part.get("base", 0), slots)
+
+
 # ---- mmread.h (C wrappers of the Matrix Market reader) --------------------------------------------------------
 spgpuMmProperties = _decl("spgpuMmProperties", i32, [C.c_char_p, ptr])
 spgpuMmReadCoo = _decl("spgpuMmReadCoo", i32, [C.c_char_p, C.c_char, ptr, ptr, ptr])

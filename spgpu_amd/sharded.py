@@ -122,9 +122,17 @@ class ShardedSpmm:
     """
 
     def __init__(self, dist, rank, world, col_blocks, own, rest, local_product, new_full_x, comm_stream=None,
-                 needed=None):
+                 needed=None, products_stream=None):
         """needed: sorted unique X rows `rest` reads (needed_rows_of), with rest's columns already renumbered into
-        that list -> a step exchanges only those rows.  None: a step all-gathers X (rest indexes the whole of X)."""
+        that list -> a step exchanges only those rows.  None: a step all-gathers X (rest indexes the whole of X).
+
+        Stream contract: the torch ops of a step (row packing, the collective, work.wait()) go to torch's CURRENT stream;
+        `local_product` launches wherever the caller's library launches (the C ABI: the handle's stream).  A step is only
+        correct when the two are the same stream, i.e. when the caller runs step() under `with torch.cuda.stream(s)` with s
+        the handle's stream.  products_stream: that stream's raw address (stream.cuda_stream); when given, every step
+        checks it and raises instead of computing on data that may not have landed.  (The C driver,
+        include/spgpu/sharded.h, orders its own streams with events and has no such requirement.)"""
+        self.products_stream = products_stream
         self.dist, self.rank, self.world = dist, rank, world
         self.needed = NeededRows(dist, rank, world, col_blocks, needed, new_full_x) if needed is not None else None
         self.col_blocks = col_blocks                  # [(first, count)] ownership of X rows per rank
@@ -157,6 +165,11 @@ class ShardedSpmm:
 
     def step(self, z_local, y_local, alpha, x_local, beta):
         """One sharded product.  With a split block the own-column part overlaps the all-gather."""
+        if self.products_stream is not None:
+            import torch
+            if torch.cuda.current_stream().cuda_stream != self.products_stream:
+                raise RuntimeError("ShardedSpmm.step: torch's current stream is not the stream the products run on; "
+                                   "wrap the step in `with torch.cuda.stream(handle_stream)` (see the class docstring)")
         if self.rest is None:
             work = self.gather_x(x_local)
             if work is not None:

@@ -1,3 +1,6 @@
 cd /root/repo
-timeout -k 10 900 python -m pytest tests/test_gpu_oell_device.py tests/test_gpu_spmv.py tests/test_gpu_f3.py -x -q 2>&1 | tail -3
-EXP_PATTERNS=near2048,banded timeout -k 10 300 python tools/exp_tile.py D 10000000 uniform 2>&1 | grep "^D "
+timeout -k 10 600 python -m pytest tests/test_gpu_sharded_c.py tests/test_gpu_bench_rehearsal.py -x -q 2>&1 | tail -8
+echo "--- bench spmm 1 rank, RCCL initialised, forced split, C driver"
+SPGPU_BENCH_FORCE_DIST=1 timeout -k 10 300 python bench.py --workload spmm --force-split --steps 20 --warmup 5 2>&1 | tail -2 | cut -c1-1500
+echo "--- bench spmm 1 rank, no dist"
+timeout -k 10 300 python bench.py --workload spmm --steps 20 --warmup 5 2>&1 | tail -1 | cut -c1-1200
