@@ -56,6 +56,8 @@ void spgpuTuningReload(void);
 #define SPGPU_SPMV_FORM_XTILE  3
 void spgpuSetSpmvForm(spgpuHandle_t handle, int form);
 int spgpuGetSpmvForm(spgpuHandle_t handle);
+/* Diagnostic: the form (GATHER / STRIPS / XTILE) the most recent ELL/HELL SpMV call on this handle was launched in. */
+int spgpuGetLastSpmvForm(spgpuHandle_t handle);
 
 #ifdef __cplusplus
 }

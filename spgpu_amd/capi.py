@@ -245,6 +245,7 @@ for _L in "SD":
 FORM_AUTO, FORM_GATHER, FORM_STRIPS, FORM_XTILE = range(4)
 spgpuSetSpmvForm = _decl("spgpuSetSpmvForm", None, [Handle, i32])
 spgpuGetSpmvForm = _decl("spgpuGetSpmvForm", i32, [Handle])
+spgpuGetLastSpmvForm = _decl("spgpuGetLastSpmvForm", i32, [Handle])
 
 # ---- tuning.h: environment knobs are cached by the library; call after changing one ---------------------------
 spgpuTuningReload = _decl("spgpuTuningReload", None, [])

@@ -202,6 +202,16 @@ int spgpuGetSpmvForm(spgpuHandle_t pHandle)
     return __atomic_load_n(&spgpuPrivate(pHandle)->spmvForm, __ATOMIC_RELAXED);
 }
 
+int spgpuGetLastSpmvForm(spgpuHandle_t pHandle)
+{
+    return __atomic_load_n(&spgpuPrivate(pHandle)->lastSpmvForm, __ATOMIC_RELAXED);
+}
+
+void spgpuNoteSpmvForm(spgpuHandle_t pHandle, int form)
+{
+    __atomic_store_n(&spgpuPrivate(pHandle)->lastSpmvForm, form, __ATOMIC_RELAXED);
+}
+
 /* ---- tuning knobs (include/spgpu/tuning.h) ---- */
 static SpgpuTuning tuning;
 static int tuningLoaded;

@@ -70,7 +70,8 @@ template <typename T> struct SlabArgs {
     long long valStride, idxStride; /* elements between two slab columns */
     int wideIO;   /* y and z are aligned for RPL-wide access */
     int tailLanes; /* TAIL kernels: switch to whole-wave rows when <= this many lanes are busy */
-    int* feedback; /* STRIPS kernels: pinned host ints the sample wavefronts report their form to, or NULL */
+    int* feedback; /* pinned host ints the sample wavefronts report the form they saw to, or NULL */
+    long long tileSpanLimit; /* a sample group whose columns span at most this many counts as "local" (x-tile form) */
     /* DEEP kernels: 32-row sub-groups deeper than deepCap hand their columns >= deepCap to deepSpmvKernel */
     int deepCap;
     int* deepCounts;             /* [SPGPU_DEEP_QUEUES] entries registered per queue (may exceed the queue's capacity) */
@@ -137,7 +138,7 @@ __device__ inline long long sampleGroup(long long groups, int q)
  *        counts, so a placement / allocation effect), and the host picks per matrix (launchSlabFamily).
  */
 template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PIPE, bool TAIL, int XPOLICY = 0, bool STRIPS = false,
-          int BLOCK = kBlockThreads, int TILE_BYTES = 0, bool DEEP = false, int GPW = 1>
+          int BLOCK = kBlockThreads, int TILE_BYTES = 0, bool DEEP = false, int GPW = 1, int TAIL_EVERY = 0>
 __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
@@ -444,6 +445,31 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
         return __ballot(scattered) == 0ull;
     };
 
+    /* the sample wavefronts: first to last column over the group's rows (their first and last entries: the extremes of
+     * rows whose columns ascend), or "unbounded" if an index lies below the base */
+    auto columnSpan = [&]() -> long long { /* call with the whole wavefront */
+        int lowest = 0x7fffffff, highest = -1;
+        bool below = false;
+        if (phase == 0) {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t) {
+                if (len[t] > 0) {
+                    const int f = idxs[t] - a.baseIndex, l = idxs[t + (long long)(len[t] - 1) * a.idxStride] - a.baseIndex;
+                    below |= f < 0 || l < 0;
+                    lowest = f < lowest ? f : lowest;
+                    lowest = l < lowest ? l : lowest;
+                    highest = f > highest ? f : highest;
+                    highest = l > highest ? l : highest;
+                }
+            }
+        }
+        lowest = waveMin(lowest);
+        highest = waveMax(highest);
+        if (__ballot(below) != 0ull)
+            return 1ll << 40;
+        return highest < lowest ? 0ll : (long long)highest - lowest + 1;
+    };
+
     constexpr int STEP = PH * UNROLL;
     /* TAIL: when at most kTailLanes lanes of the wavefront still have entries left, the
      * slab loop would run on with >= 7/8 of its lanes idle (ragged matrices: one long row keeps a whole
@@ -451,9 +477,13 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
      * WHOLE wavefront: lane l takes entries tailFrom + l, + 64, ...; the 64 partial sums are combined
      * with lane-xor shuffles and added to the owner lane's running sum. */
     int tailFrom = groupLongest;
+    /* TAIL_EVERY: the switch is only considered at multiples of that many columns -- a kernel with shorter stages then
+     * adds every row in exactly the order of the kernel whose stage is TAIL_EVERY columns (the x-tile form of the fp64
+     * kernels has 4-column stages and must give the bits of the 8-column gather / strip kernels it alternates with) */
+    constexpr int TAIL_STRIDE = TAIL_EVERY > 0 ? TAIL_EVERY : PH * UNROLL;
     auto switchToTail = [&](int kBase) -> bool {
         if constexpr (TAIL) {
-            if (__popcll(__ballot(kBase < laneLongest)) <= a.tailLanes) {
+            if (kBase % TAIL_STRIDE == 0 && __popcll(__ballot(kBase < laneLongest)) <= a.tailLanes) {
                 tailFrom = kBase;
                 return true;
             }
@@ -487,15 +517,19 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
                     break; /* scattered columns: the gather loop takes over from this stage */
                 stage(std::true_type{});
             }
-            /* three sample wavefronts tell the host which form this matrix runs in (launchSlabFamily) */
+            /* three sample wavefronts tell the host which form this matrix runs in (launchSlabFamily): 2 strips,
+             * 3 columns inside a window an LDS tile holds, 1 scattered */
             if (a.feedback) {
                 const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
-                for (int q = 1; q <= 3; ++q)
-                    if (group == sampleGroup(groups, q) && lane == 0)
-                        /* at least half of it as strips -- and more than one stage of it: the test costs about a
-                         * third of a stage, which a single stage of strips does not earn back (5-point Laplacian,
-                         * 16.7 M rows: 258 us with it, 251 us as gathers) */
-                        a.feedback[q - 1] = 2 * kBase >= groupLongest && groupLongest > STEP ? 2 : 1;
+                if (group == sampleGroup(groups, 1) || group == sampleGroup(groups, 2) || group == sampleGroup(groups, 3)) {
+                    const int other = columnSpan() <= a.tileSpanLimit ? 3 : 1;
+                    for (int q = 1; q <= 3; ++q)
+                        if (group == sampleGroup(groups, q) && lane == 0)
+                            /* at least half of it as strips -- and more than one stage of it: the test costs about a
+                             * third of a stage, which a single stage of strips does not earn back (5-point Laplacian,
+                             * 16.7 M rows: 258 us with it, 251 us as gathers) */
+                            a.feedback[q - 1] = 2 * kBase >= groupLongest && groupLongest > STEP ? 2 : other;
+                }
             }
         }
         else if constexpr (RPL > 1 && XPOLICY == 0) {
@@ -513,9 +547,10 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
                         if (!stageIsStrips(asStrips, probe))
                             break;
                     }
+                    const int other = columnSpan() <= a.tileSpanLimit ? 3 : 1;
                     for (int q = 1; q <= 3; ++q)
                         if (group == sampleGroup(groups, q) && lane == 0)
-                            a.feedback[q - 1] = 2 * asStrips >= groupLongest && groupLongest > STEP ? 2 : 1;
+                            a.feedback[q - 1] = 2 * asStrips >= groupLongest && groupLongest > STEP ? 2 : other;
                 }
             }
         }
@@ -829,14 +864,15 @@ static void launchSlab(hipStream_t stream, const SlabArgs<T>& a, bool nt)
  *   1  one wavefront per 32-row group (PH = 2 * RPL, 2 columns per stage), 512 lanes, 64 KiB  (no deep split)
  *   2  512 lanes, 64 KiB      3  256 lanes, 48 KiB
  * The coefficient/index streams always carry the non-temporal hint here. */
-template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool TAIL, int BLOCK, int TILE_BYTES, bool DEEP, int GPW = 1>
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool TAIL, int BLOCK, int TILE_BYTES, bool DEEP, int GPW = 1,
+          int TAIL_EVERY = 0>
 static void launchShape(hipStream_t stream, const SlabArgs<T>& a)
 {
     constexpr int GROUP_ROWS = (kWave / PH) * RPL;
     constexpr int WAVES = BLOCK / kWave;
     const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
     const unsigned blocks = (unsigned)((groups + WAVES * GPW - 1) / (WAVES * GPW));
-    hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, 2, TAIL, 0, false, BLOCK, TILE_BYTES, DEEP, GPW>),
+    hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, 2, TAIL, 0, false, BLOCK, TILE_BYTES, DEEP, GPW, TAIL_EVERY>),
                        dim3(blocks), dim3(BLOCK), 0, stream, a);
 }
 
@@ -856,7 +892,19 @@ static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
     case 3: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 49152, DEEP, 2>(stream, a); break;
     case 4: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 65536, DEEP, 2>(stream, a); break;
     case 5: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 512, 65536, DEEP, 2>(stream, a); break;
-    default: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 32768, DEEP>(stream, a); break;
+    default:
+        /* the default: same summation order as the type's gather / strip kernel (launchSlabFamily), so that the form
+         * AUTO settles on never changes a bit of the result: 8-byte elements walk whole rows and consider the tail every
+         * 8 columns; fp32 keeps its 8 phases x 2 columns; complex fp64 its 2 phases */
+        if constexpr (DEEP)
+            launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 32768, true>(stream, a);
+        else if constexpr (sizeof(T) == 4 && RPL == 4)
+            launchShape<T, RPL, 2 * RPL, IS_HELL, 2, true, 512, 32768, false>(stream, a);
+        else if constexpr (sizeof(T) == 8 && RPL == 2)
+            launchShape<T, RPL, 1, IS_HELL, 4, true, 256, 32768, false, 1, 8>(stream, a);
+        else
+            launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 32768, false>(stream, a);
+        break;
     }
 }
 
@@ -940,6 +988,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
          * caller asked for plain gathers */
         a.wideIO = 0;
         a.feedback = nullptr;
+        spgpuNoteSpmvForm(handle, form != SPGPU_SPMV_FORM_GATHER ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
         launchRagged<T, WIDE, IS_HELL, true>(stream, a, tune->raggedShape, form != SPGPU_SPMV_FORM_GATHER);
         launchDeep<T, WIDE, IS_HELL>(stream, a);
         return;
@@ -948,6 +997,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         /* shapes in which a lane walks whole rows, for every type; the strip form does not apply to ordered rows */
         a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
         a.feedback = nullptr;
+        spgpuNoteSpmvForm(handle, tiled ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
         if (tiled)
             launchTiled<T, WIDE, IS_HELL, true>(stream, a, tune->xTileShape);
         else
@@ -955,21 +1005,29 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         launchDeep<T, WIDE, IS_HELL>(stream, a);
         return;
     }
-    bool strips = false;
+    bool strips = false, autoTile = false;
     a.feedback = nullptr;
+    a.tileSpanLimit = (long long)(32768 / sizeof(T)) * 5 / 4; /* 1.25 x the default tile (launchTiled, shape 0) */
     if (!narrowVariant && WIDE > 1 && !tiled) {
         if (form != SPGPU_SPMV_FORM_AUTO) {
             strips = form == SPGPU_SPMV_FORM_STRIPS;
         } else {
             int* seen = spgpuFormFeedback(handle, a.rP, a.rows);
-            int gathers = 0;
-            for (int q = 0; q < 3; ++q)
-                gathers += ((volatile int*)seen)[q] == 1 ? 1 : 0;
-            strips = gathers < 2;
-            a.feedback = seen; /* both forms report: the matrix at this address may be another one next time */
+            int gathers = 0, local = 0;
+            for (int q = 0; q < 3; ++q) {
+                const int said = ((volatile int*)seen)[q];
+                gathers += said == 1 ? 1 : 0;
+                local += said == 3 ? 1 : 0;
+            }
+            /* two of three samples decide: scattered -> gathers; inside a window -> the LDS tile; otherwise (strips, or
+             * nothing known yet) the strip-capable kernel */
+            autoTile = local >= 2 && tune->spmvVariant < 1 && (variant == 21 || variant == 22);
+            strips = gathers + local < 2;
+            a.feedback = seen; /* every form reports: the matrix at this address may be another one next time */
         }
     }
 
+    spgpuNoteSpmvForm(handle, (tiled || autoTile) ? SPGPU_SPMV_FORM_XTILE : (strips ? SPGPU_SPMV_FORM_STRIPS : SPGPU_SPMV_FORM_GATHER));
     if (!narrowVariant) {
         a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
         if constexpr (WIDE > 1) {
@@ -992,7 +1050,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
             case 17: launchSlab<T, WIDE, 1, IS_HELL, 8, 1, true>(stream, a, nt); break;
             case 22:
-                if (tiled)
+                if (tiled || autoTile)
                     launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
                 else if (strips)
                     launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true, 0, true>(stream, a, nt);
@@ -1001,7 +1059,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
                 break;
             case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;
             default: /* 21 */
-                if (tiled)
+                if (tiled || autoTile)
                     launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
                 else if (strips)
                     launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true, 0, true>(stream, a, nt);

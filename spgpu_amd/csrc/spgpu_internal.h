@@ -32,7 +32,8 @@ typedef struct SpgpuPrivateHandle {
     unsigned formNext;
     pthread_mutex_t formLock; /* guards formKey / formRows / formNext */
     int spmvForm;             /* SPGPU_SPMV_FORM_* set by spgpuSetSpmvForm (atomic) */
-    void* deepScratch;        /* device: SpgpuDeepQueue | entries | partials; NULL until first needed */
+    void* deepScratch;        /* device: queue counts | entries | partials; NULL until first needed */
+    int lastSpmvForm;         /* form of the most recent ELL/HELL SpMV launch (diagnostic, atomic) */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8
 #define SPGPU_FEEDBACK_SAMPLES 4
@@ -60,6 +61,8 @@ spgpuStatus_t spgpuDeepScratch(spgpuHandle_t h, int** counts, SpgpuDeepEntry** e
  * (kernels/cudadebug.h:12-25).  Otherwise launch errors surface through the
  * caller's own hipGetLastError(), again as in the reference. */
 void spgpuDebugCheck(spgpuHandle_t h, const char* what);
+
+void spgpuNoteSpmvForm(spgpuHandle_t h, int form);
 
 /* The feedback ints of the matrix identified by (key, rows): found or newly assigned (and zeroed). */
 int* spgpuFormFeedback(spgpuHandle_t h, const void* key, int rows);

@@ -459,6 +459,8 @@ def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0):
             return dict(group_rows=32, rows_per_lane=rpl, step=4 * rpl, tail_lanes=16, phases=2 * rpl) if rpl > 1 else None
         if letter == "Z" and not deep:
             return None
+        if tile_shape == 0 and not deep:      # the default tile shape adds in the order of the type's gather kernel
+            return dict(TAIL_SHAPE[letter])
         return dict(group_rows=64 * rpl, rows_per_lane=rpl, step=4, tail_lanes=16, phases=1, **deep)
     if deep:   # a lane walks whole rows: 8 columns per stage for 8-byte elements, 4 otherwise
         return dict(group_rows=64 * rpl, rows_per_lane=rpl, step=8 if letter in "DC" else 4, tail_lanes=16, phases=1, **deep)

@@ -299,3 +299,28 @@ def test_ragged_kernel_through_ridx_bit_exact(gpu, tuning, letter, shape, form, 
             assert dz.cpu().numpy().tobytes() == want.tobytes(), (alpha, beta, in_place)
     finally:
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+
+
+@pytest.mark.parametrize("pattern,expect", [("banded", "strips"), ("near512", "xtile"), ("random", "gather")])
+def test_auto_form_settles_on_the_matrix(gpu, pattern, expect):
+    """AUTO: sample wavefronts of every launch report what they saw and the next launch on the same arrays uses it --
+    consecutive columns -> strips, columns inside a window an LDS tile holds -> x-tile, scattered -> gathers.  The sums
+    do not depend on the form (uniform rows: every shape adds a row's products in ascending k)."""
+    import torch
+    from spgpu_amd import capi, synth
+    n = 400_000
+    h = synth.hell_uniform_on_device(n, 32, pattern, "D", 32, seed=3)
+    x = synth.device_vector(n, "D", 5)
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    results = []
+    for _ in range(4):
+        capi.hellspmv["D"](gpu, _dp(z), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), None, 32, n,
+                           _dp(x), 0.0, 0)
+        torch.cuda.synchronize()
+        results.append(z.cpu().numpy().tobytes())
+    assert capi.spgpuGetLastSpmvForm(gpu) == {"strips": capi.FORM_STRIPS, "xtile": capi.FORM_XTILE, "gather": capi.FORM_GATHER}[expect]
+    assert len(set(results)) == 1
+    sub = synth.hell_rows_to_host(h, 0, 2048)
+    assert z[:2048].cpu().numpy().tobytes() == O.default_spmv(sub, x.cpu().numpy(), None, 1.0, 0.0).tobytes()

@@ -76,6 +76,7 @@ def run(h, label, forms):
         with torch.cuda.stream(stream):
             for _ in range(3):
                 call()
+                stream.synchronize()   # AUTO reads what the previous launch's sample wavefronts reported
             a.record(stream)
             for _ in range(20):
                 call()
