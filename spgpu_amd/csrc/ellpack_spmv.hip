@@ -831,6 +831,9 @@ __global__ __launch_bounds__(WAVES * kWave) void deepSpmvKernel(const SlabArgs<T
     }
 }
 
+#ifdef SPGPU_TRACE_BLOCKS
+__device__ unsigned long long* spgpuTraceBuffer;
+#endif
 #include "ragged_spmv.hip.h"
 
 /* ---- host side ----------------------------------------------------------- */
@@ -1190,6 +1193,13 @@ static void ellCsput(spgpuHandle_t handle, ApiT* cM, const int* rP, int cMPitch,
 using namespace spgpu;
 
 extern "C" {
+
+#ifdef SPGPU_TRACE_BLOCKS
+void spgpuDebugSetTrace(unsigned long long* buffer)
+{
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(spgpu::spgpuTraceBuffer), &buffer, sizeof(buffer));
+}
+#endif
 
 void spgpuDebugCheck(spgpuHandle_t h, const char* what)
 {

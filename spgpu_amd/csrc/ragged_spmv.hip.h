@@ -47,6 +47,11 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int sub = lane % LPC, phase = lane / LPC;
+#ifdef SPGPU_TRACE_BLOCKS
+    /* experiment builds only: start / end time of every workgroup (100 MHz wall clock) into a caller-provided buffer */
+    if (spgpuTraceBuffer && threadIdx.x == 0)
+        spgpuTraceBuffer[3 * (size_t)blockIdx.x] = wall_clock64();
+#endif
     /* Consecutive workgroups (in row order) read overlapping slices of x.  The hardware deals workgroup ids round-robin
      * over the 8 XCDs, each with an L2 of its own: left alone, every slice is fetched from memory by all eight.  With
      * a.xcdRun > 0 the id is permuted so that runs of xcdRun consecutive row blocks share an XCD (speed only). */
@@ -54,54 +59,91 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
     const long long blockRow0 = (long long)logicalBlock * ROWS;
     const T* __restrict__ x = a.x;
 
-    /* ---- 1: row lengths and strip bases of the whole workgroup --------------------------------------------------- */
-    for (int i = threadIdx.x; i < ROWS; i += BLOCK) {
+    /* ---- prologue.  A workgroup lives ~35 us and streams nothing while it finds out where its rows are, so the
+     * dependent memory round trips here are counted: (1) row lengths and hack offsets, (2) the first and last column
+     * of every row (where is the slice of x?) and the deep registrations, (3) the slice of x itself, in ONE round of
+     * loads, together with the first stages of the stream.  Measured with 4 round trips and 4 barriers: 12.7 us, a
+     * third of a workgroup's life (profiles/r02b_ragged_workgroup_trace.txt). ------------------------------------- */
+    constexpr int RPT = (ROWS + BLOCK - 1) / BLOCK; /* rows a thread looks at; 32 consecutive rows = 32 consecutive lanes */
+    int myLen[RPT], myBase[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) { /* round trip 1 */
+        const int i = threadIdx.x + j * BLOCK;
         const long long r = blockRow0 + i;
-        lens[i] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
-    }
-    for (int i = threadIdx.x; i < ROWS / RPL; i += BLOCK) {
-        const long long r0 = blockRow0 + (long long)i * RPL;
-        int at = 0;
-        if (r0 < a.rows) {
+        const bool live = i < ROWS && r < a.rows;
+        myLen[j] = live ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+        myBase[j] = 0;
+        if (live) {
             if constexpr (IS_HELL) {
-                const unsigned u0 = (unsigned)r0, hs = (unsigned)a.hackSize;
-                at = a.hackOffsets[u0 / hs] + (int)(u0 % hs);
+                const unsigned u0 = (unsigned)r, hs = (unsigned)a.hackSize;
+                myBase[j] = a.hackOffsets[u0 / hs] + (int)(u0 % hs);
             } else {
-                at = (int)r0;
+                myBase[j] = (int)r;
             }
         }
-        bases[i] = at;
+    }
+    ColumnProbe mine{0x7fffffff, -0x7fffffff - 1, 0, 0};
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) { /* round trip 2 */
+        const int i = threadIdx.x + j * BLOCK;
+        int first = 0, last = 0;
+        if (XTILE && myLen[j] > 0) {
+            first = a.rP[myBase[j]];
+            last = a.rP[myBase[j] + (long long)(myLen[j] - 1) * a.idxStride];
+        }
+        /* depth of the 32-row sub-group these 32 lanes hold; the deep ones register and are cut at deepCap */
+        int depth = myLen[j];
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) {
+            const int other = laneXor(depth, m);
+            depth = other > depth ? other : depth;
+        }
+        int slot = -1;
+        if constexpr (DEEP) {
+            if ((lane & 31) == 0 && depth > a.deepCap && i < ROWS) {
+                const long long sub0 = (blockRow0 + i) >> 5;
+                const int queue = (int)(sub0 % SPGPU_DEEP_QUEUES);
+                const int at = atomicAdd(&a.deepCounts[queue], 1);
+                if (at < SPGPU_DEEP_QUEUE_ENTRIES) {
+                    slot = queue * SPGPU_DEEP_QUEUE_ENTRIES + at;
+                    a.deepEntries[slot] = SpgpuDeepEntry{(int)(sub0 << 5), depth};
+                }
+            }
+            slot = __shfl(slot, lane & 32, kWave);
+        }
+        if (i < ROWS) {
+            lens[i] = (slot >= 0 && myLen[j] > a.deepCap) ? a.deepCap : myLen[j];
+            if (i % RPL == 0)
+                bases[i / RPL] = myBase[j];
+            if ((lane & 31) == 0) {
+                depths[i >> 5] = (slot >= 0 && depth > a.deepCap) ? a.deepCap : depth;
+                deepSlots[i >> 5] = slot;
+            }
+        }
+        if (XTILE && myLen[j] > 0) {
+            const int f = first - a.baseIndex, l = last - a.baseIndex;
+            const int low = f < l ? f : l, high = f < l ? l : f;
+            mine.lowest = low < mine.lowest ? low : mine.lowest;
+            mine.highest = high > mine.highest ? high : mine.highest;
+            mine.middles += ((long long)f + l) >> 1;
+            mine.rows += 1;
+        }
+    }
+    if constexpr (XTILE) {
+        mine.lowest = waveMin(mine.lowest);
+        mine.highest = waveMax(mine.highest);
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) {
+            mine.rows += laneXor(mine.rows, m);
+            const int lowHalf = laneXor((int)(unsigned)(mine.middles & 0xffffffffll), m);
+            const int highHalf = laneXor((int)(mine.middles >> 32), m);
+            mine.middles += ((long long)highHalf << 32) | (unsigned)lowHalf;
+        }
+        if (lane == 0)
+            seen[wave] = mine;
     }
     if (threadIdx.x == 0)
         nextItem = WAVES; /* the first WAVES sub-groups are dealt out statically */
-    __syncthreads();
-
-    /* ---- 2: depth of every sub-group; the deep ones register and are cut at deepCap ------------------------------ */
-    for (int s = wave; s < SUBS; s += WAVES) {
-        const int mine = lane < 32 ? lens[s * 32 + lane] : 0;
-        const int depth = waveMax(mine);
-        int slot = -1;
-        if constexpr (DEEP) {
-            if (depth > a.deepCap) {
-                if (lane == 0) {
-                    const long long sub0 = (blockRow0 >> 5) + s;
-                    const int queue = (int)(sub0 % SPGPU_DEEP_QUEUES);
-                    const int at = atomicAdd(&a.deepCounts[queue], 1);
-                    if (at < SPGPU_DEEP_QUEUE_ENTRIES) {
-                        slot = queue * SPGPU_DEEP_QUEUE_ENTRIES + at;
-                        a.deepEntries[slot] = SpgpuDeepEntry{(int)(sub0 << 5), depth};
-                    }
-                }
-                slot = __shfl(slot, 0, kWave);
-                if (slot >= 0 && lane < 32 && mine > a.deepCap)
-                    lens[s * 32 + lane] = a.deepCap;
-            }
-        }
-        if (lane == 0) {
-            depths[s] = (slot >= 0 && depth > a.deepCap) ? a.deepCap : depth;
-            deepSlots[s] = slot;
-        }
-    }
     __syncthreads();
 
     /* ---- the per-sub-group state of a lane, and the stage loads --------------------------------------------------- */
@@ -142,43 +184,61 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
         }
     };
 
-    /* the wavefront's first sub-group: its first stage is on its way while the tile is being placed and filled */
-    int s = wave;
-    Item now, then;
-    Stage cur, nxt;
-    loadItem(s, now);
-    fetch(now, 0, cur);
+    /* The stream of stages a wavefront walks: the stages of its first sub-group, then of the sub-groups it takes from the
+     * queue.  A fetch cursor runs AHEAD stages in front of the stage being consumed, so that AHEAD stage loads (3 KiB
+     * each for 8-byte elements at UNROLL 2 ... 6 KiB at 4) are in flight per wavefront: with one stage ahead a
+     * wavefront waits a full memory round trip per stage (measured: 1.25 GB/s per wavefront, 10 GB/s per workgroup).
+     * A ring slot holds a stage and what consuming it needs to know. */
+    constexpr int AHEAD = 2;
+    struct Slot {
+        Stage st;
+        int len[RPL];
+        int s;      /* sub-group (>= SUBS: nothing, the stream has ended) */
+        int kBase;
+        bool last;  /* last stage of its sub-group */
+    };
+    auto grab = [&]() -> int {
+        int got = 0;
+        if (lane == 0)
+            got = atomicAdd(&nextItem, 1);
+        return __builtin_amdgcn_readfirstlane(got);
+    };
+    /* fetch cursor */
+    int fs = wave, fk = 0, fsThen = SUBS; /* fsThen: grabbed one sub-group ahead (after the prologue's barrier) */
+    Item fit;
+    loadItem(fs, fit);
+    auto fetchNext = [&](Slot& slot) {
+        slot.s = fs;
+        slot.kBase = fk;
+        if (fs < SUBS) {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                slot.len[t] = fit.len[t];
+            fetch(fit, fk, slot.st);
+            fk += STEP;
+            slot.last = fk >= fit.depth;
+            if (slot.last) { /* wavefront-uniform: on to the next sub-group */
+                fs = fsThen;
+                fk = 0;
+                if (fs < SUBS)
+                    loadItem(fs, fit);
+                fsThen = fs < SUBS ? grab() : SUBS;
+            }
+        } else {
+            slot.last = false;
+        }
+    };
+    Slot ring[AHEAD + 1];
 
-    /* ---- 3: which slice of x?  (see slabSpmvKernel, XTILE) ------------------------------------------------------- */
+    fsThen = grab();
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i)
+        fetchNext(ring[i]); /* on their way while the tile is being placed and filled */
+
+    /* ---- the slice of x (round trip 3; the stages requested just above travel with it) ---------------------------- */
     int tileBase = 0;
     unsigned tileCount = 0;
     if constexpr (XTILE) {
-        ColumnProbe mine{0x7fffffff, -0x7fffffff - 1, 0, 0};
-        for (int i = threadIdx.x; i < ROWS; i += BLOCK) {
-            const int len = lens[i];
-            if (len > 0) {
-                const long long at = (long long)bases[i / RPL] + i % RPL;
-                const int f = a.rP[at] - a.baseIndex;
-                const int l = a.rP[at + (long long)(len - 1) * a.idxStride] - a.baseIndex;
-                const int low = f < l ? f : l, high = f < l ? l : f;
-                mine.lowest = low < mine.lowest ? low : mine.lowest;
-                mine.highest = high > mine.highest ? high : mine.highest;
-                mine.middles += ((long long)f + l) >> 1;
-                mine.rows += 1;
-            }
-        }
-        mine.lowest = waveMin(mine.lowest);
-        mine.highest = waveMax(mine.highest);
-#pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) {
-            mine.rows += laneXor(mine.rows, m);
-            const int lowHalf = laneXor((int)(unsigned)(mine.middles & 0xffffffffll), m);
-            const int highHalf = laneXor((int)(mine.middles >> 32), m);
-            mine.middles += ((long long)highHalf << 32) | (unsigned)lowHalf;
-        }
-        if (lane == 0)
-            seen[wave] = mine;
-        __syncthreads();
         ColumnProbe all{0x7fffffff, -0x7fffffff - 1, 0, 0};
 #pragma unroll
         for (int w = 0; w < WAVES; ++w) {
@@ -202,126 +262,123 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
             }
         }
         constexpr int PIECE = 16 / (int)sizeof(T);
+        constexpr int ROUND = (TILE_ELEMS / PIECE + BLOCK - 1) / BLOCK; /* 16-byte pieces per lane: all in flight at once */
         const T* __restrict__ from = x + tileBase;
         const unsigned pieces = tileCount / PIECE;
-        for (unsigned p0 = threadIdx.x; p0 < pieces; p0 += 4u * BLOCK) {
-            Pack<T, PIECE> w[4];
+        Pack<T, PIECE> w[ROUND];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (p0 + q * BLOCK < pieces)
-                    w[q] = loadPackElementAligned<T, PIECE>(from + (size_t)(p0 + q * BLOCK) * PIECE);
+        for (int q = 0; q < ROUND; ++q)
+            if (threadIdx.x + q * BLOCK < pieces)
+                w[q] = loadPackElementAligned<T, PIECE>(from + (size_t)(threadIdx.x + q * BLOCK) * PIECE);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (p0 + q * BLOCK < pieces)
-                    storePack<T, PIECE>(tile + (size_t)(p0 + q * BLOCK) * PIECE, w[q]);
-        }
+        for (int q = 0; q < ROUND; ++q)
+            if (threadIdx.x + q * BLOCK < pieces)
+                storePack<T, PIECE>(tile + (size_t)(threadIdx.x + q * BLOCK) * PIECE, w[q]);
         if (pieces * PIECE + threadIdx.x < tileCount)
             tile[pieces * PIECE + threadIdx.x] = from[pieces * PIECE + threadIdx.x];
         __syncthreads();
     }
 
-    /* ---- 4: sub-groups from the queue ----------------------------------------------------------------------------- */
-    auto grab = [&]() -> int {
-        int got = 0;
-        if (lane == 0)
-            got = atomicAdd(&nextItem, 1);
-        return __builtin_amdgcn_readfirstlane(got);
-    };
-    int sThen = grab(); /* known one sub-group ahead, so that its first stage can be requested in time */
+#ifdef SPGPU_TRACE_BLOCKS
+    if (spgpuTraceBuffer && threadIdx.x == 0)
+        spgpuTraceBuffer[3 * (size_t)blockIdx.x + 2] = wall_clock64(); /* tile in place */
+#endif
+    /* ---- 4: the stage stream -------------------------------------------------------------------------------------- */
     const bool hasBeta = isNotZero(a.beta);
+    T sum[RPL];
+#pragma unroll
+    for (int t = 0; t < RPL; ++t)
+        sum[t] = zeroOf<T>();
 
-    while (s < SUBS) {
-        T sum[RPL];
+    /* consume the stage in `cur`; request the stage AHEAD further on into `refill` (the slot consumed last) */
+    auto step = [&](Slot& cur, Slot& refill) {
+        T xv[UNROLL][RPL];
+        bool use[UNROLL][RPL];
 #pragma unroll
-        for (int t = 0; t < RPL; ++t)
-            sum[t] = zeroOf<T>();
-        const int stages = now.depth > 0 ? (now.depth + STEP - 1) / STEP : 1; /* an empty sub-group still hands over */
-        for (int stage = 0; stage < stages; ++stage) {
-            const int kBase = stage * STEP;
-            T xv[UNROLL][RPL];
-            bool use[UNROLL][RPL];
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = cur.kBase + u * PH + phase;
+            if constexpr (XTILE) {
+                bool outside = false;
+                unsigned at[RPL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int k = kBase + u * PH + phase;
-                if constexpr (XTILE) {
-                    bool outside = false;
-                    unsigned at[RPL];
-#pragma unroll
-                    for (int t = 0; t < RPL; ++t) {
-                        const int col = cur.c[u].v[t] - a.baseIndex;
-                        use[u][t] = k < now.len[t] && col >= 0;
-                        at[t] = (unsigned)(col - tileBase);
-                        const bool inside = at[t] < tileCount;
-                        outside |= use[u][t] && !inside;
-                        xv[u][t] = tile[inside ? at[t] : 0u];
-                    }
-                    if (__ballot(outside) != 0ull) {
-#pragma unroll
-                        for (int t = 0; t < RPL; ++t) {
-                            if (use[u][t] && at[t] >= tileCount)
-                                xv[u][t] = x[cur.c[u].v[t] - a.baseIndex];
-                        }
-                    }
-                } else {
+                for (int t = 0; t < RPL; ++t) {
+                    const int col = cur.st.c[u].v[t] - a.baseIndex;
+                    use[u][t] = k < cur.len[t] && col >= 0;
+                    at[t] = (unsigned)(col - tileBase);
+                    const bool inside = at[t] < tileCount;
+                    outside |= use[u][t] && !inside;
+                    xv[u][t] = tile[inside ? at[t] : 0u];
+                }
+                if (__ballot(outside) != 0ull) {
 #pragma unroll
                     for (int t = 0; t < RPL; ++t) {
-                        const int col = cur.c[u].v[t] - a.baseIndex;
-                        use[u][t] = k < now.len[t] && col >= 0;
-                        xv[u][t] = x[use[u][t] ? col : 0];
+                        if (use[u][t] && at[t] >= tileCount)
+                            xv[u][t] = x[cur.st.c[u].v[t] - a.baseIndex];
                     }
                 }
-            }
-            /* behind the x reads in issue order: the next stage of this sub-group, or the first of the next one
-             * (one fetch, its source chosen by a wavefront-uniform test: two fetches cost 40 VGPRs) */
-            const bool lastStage = stage + 1 >= stages;
-            if (lastStage) {
-                if (sThen < SUBS)
-                    loadItem(sThen, then);
-                else
-                    then.longest = 0; /* nothing follows: the fetch below loads nothing */
-            }
-            Item from = now;
-            if (lastStage)
-                from = then;
-            fetch(from, lastStage ? 0 : kBase + STEP, nxt);
+            } else {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-#pragma unroll
-                for (int t = 0; t < RPL; ++t)
-                    sum[t] = pick(use[u][t], mulAdd(cur.v[u].v[t], xv[u][t], sum[t]), sum[t]);
+                for (int t = 0; t < RPL; ++t) {
+                    const int col = cur.st.c[u].v[t] - a.baseIndex;
+                    use[u][t] = k < cur.len[t] && col >= 0;
+                    xv[u][t] = x[use[u][t] ? col : 0];
+                }
             }
-            cur = nxt;
         }
+        const int s = cur.s;
+        const bool last = cur.last;
+        fetchNext(refill); /* behind the x reads in issue order */
 #pragma unroll
-        for (int m = LPC; m < kWave; m <<= 1) {
+        for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
             for (int t = 0; t < RPL; ++t)
-                sum[t] = add(sum[t], laneXor(sum[t], m));
+                sum[t] = pick(use[u][t], mulAdd(cur.st.v[u].v[t], xv[u][t], sum[t]), sum[t]);
         }
-        if (phase == 0) {
-            const int deepSlot = deepSlots[s];
+        if (last) { /* wavefront-uniform: the sub-group is complete */
 #pragma unroll
-            for (int t = 0; t < RPL; ++t) {
-                const long long r = blockRow0 + s * 32 + sub * RPL + t;
-                if (r < a.rows) {
-                    if (DEEP && deepSlot >= 0) {
-                        a.deepPartials[(size_t)deepSlot * 32 + (size_t)(sub * RPL + t)] = sum[t];
-                    } else {
-                        const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
-                        a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
-                                              : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
+            for (int m = LPC; m < kWave; m <<= 1) {
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    sum[t] = add(sum[t], laneXor(sum[t], m));
+            }
+            if (phase == 0) {
+                const int deepSlot = deepSlots[s];
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    const long long r = blockRow0 + s * 32 + sub * RPL + t;
+                    if (r < a.rows) {
+                        if (DEEP && deepSlot >= 0) {
+                            a.deepPartials[(size_t)deepSlot * 32 + (size_t)(sub * RPL + t)] = sum[t];
+                        } else {
+                            const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+                            a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
+                                                  : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
+                        }
                     }
                 }
             }
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                sum[t] = zeroOf<T>();
         }
-        s = sThen;
-        now = then;
-        sThen = grab();
+    };
+    static_assert(AHEAD == 2, "the rotation below is written out for a ring of three");
+    for (;;) { /* the ring rotates by name, not by copying registers */
+        if (ring[0].s >= SUBS) break;
+        step(ring[0], ring[2]);
+        if (ring[1].s >= SUBS) break;
+        step(ring[1], ring[0]);
+        if (ring[2].s >= SUBS) break;
+        step(ring[2], ring[1]);
     }
+#ifdef SPGPU_TRACE_BLOCKS
+    if (spgpuTraceBuffer && lane == 0)
+        atomicMax(&spgpuTraceBuffer[3 * (size_t)blockIdx.x + 1], (unsigned long long)wall_clock64());
+#endif
 }
 
 #ifndef SPGPU_RAGGED_UNROLL
-#define SPGPU_RAGGED_UNROLL(RPL) ((RPL) >= 4 ? 2 : 4) /* wave-wide loads per stage: 16 slab columns for 4- and 8-byte elements */
+#define SPGPU_RAGGED_UNROLL(RPL) ((RPL) >= 4 ? 2 : 3) /* wave-wide loads per stage; 3 keeps the 8-byte kernels at 112 VGPRs (4 wavefronts per SIMD: two 8-wavefront workgroups per CU) with two stages in flight */
 #endif
 /* Shapes (SPGPU_RAGGED_SHAPE; 0 is the default): workgroup lanes / tile / sub-groups per workgroup. */
 template <typename T, int RPL, bool IS_HELL, bool DEEP>

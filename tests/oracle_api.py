@@ -453,7 +453,7 @@ def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0):
     deep = dict(deep_cap=deep_cap, **DEEP_SHAPE[letter]) if deep_cap > 0 else {}
     if form == "ragged":   # raggedSpmvKernel: one wavefront per 32-row sub-group, 64 / (32 / rpl) phases, no tail rows
         phases = 2 * rpl
-        return dict(group_rows=32, rows_per_lane=rpl, step=phases * (2 if rpl >= 4 else 4), tail_lanes=0, phases=phases, **deep)
+        return dict(group_rows=32, rows_per_lane=rpl, step=phases * (2 if rpl >= 4 else 3), tail_lanes=0, phases=phases, **deep)
     if form == "xtile":
         if tile_shape == 1 and not deep:
             return dict(group_rows=32, rows_per_lane=rpl, step=4 * rpl, tail_lanes=16, phases=2 * rpl) if rpl > 1 else None
