@@ -44,8 +44,11 @@ void ellToOell(int* rIdx, void* dstEllValues, int* dstEllIndices, int* dstRs, co
  *   window  > 0: rows are sorted inside consecutive windows of `window` rows only, so that position i stays within
  *                `window` rows of its original place (x and z keep their locality); windows alternate between
  *                descending and ascending (length, row) order so that rows of similar length meet where two windows meet.
- *   longRows > 0: rows LONGER than longRows are taken out of their windows and come first, sorted among themselves
- *                (descending): a handful of very long rows otherwise sets the depth of one hack per window. */
+ *   longRows > 0: rows LONGER than longRows are taken out of their windows and come first, sorted inside windows of
+ *                their own, SPGPU_OELL_LONG_WINDOW_FACTOR times as large (one window when window <= 0): a handful of very
+ *                long rows otherwise sets the depth of one hack per window, and sorted over the whole matrix the 32 rows of
+ *                one of their hacks would come from everywhere (every x gather a cache line from memory). */
+#define SPGPU_OELL_LONG_WINDOW_FACTOR 32
 void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows);
 
 #ifdef __cplusplus

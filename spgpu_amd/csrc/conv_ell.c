@@ -65,11 +65,12 @@ void cooToEll(void* ellValues, int* ellIndices, int ellValuesPitch, int ellIndic
 
 /* ---- row order by length ------------------------------------------------------------------------------------
  * oellOrder (include/spgpu/ell_conv.h): the general form of the order the reference's ellToOell computes.
- * Rows fall into groups -- group 0: rows longer than longRows (when longRows > 0), group 1 + r / window: the
- * others (one group when window <= 0) -- and the groups follow each other in ascending number.  Inside a group
- * rows descend by (length, row) in group 0 and in every other group from the first; the groups in between ascend
- * by (length, row), so that where two windows meet, rows of similar length meet. */
-typedef struct { unsigned group; int len; int row; } OellKey;
+ * Rows fall into groups.  The rows longer than longRows (when longRows > 0) come first, in windows of
+ * SPGPU_OELL_LONG_WINDOW_FACTOR * window rows (one group when window <= 0); then the others in windows of `window`
+ * rows (one group when window <= 0).  Groups follow each other in ascending window inside each class.  Inside a
+ * group rows descend by (length, row) in the first window of a class and in every other one from there; the windows in
+ * between ascend by (length, row), so that where two windows meet, rows of similar length meet. */
+typedef struct { unsigned group; int descending; int len; int row; } OellKey;
 
 static int oellKeyCompare(const void* pa, const void* pb)
 {
@@ -77,9 +78,8 @@ static int oellKeyCompare(const void* pa, const void* pb)
     const OellKey* b = (const OellKey*)pb;
     if (a->group != b->group)
         return a->group < b->group ? -1 : 1;
-    const int descending = a->group == 0 || (a->group - 1) % 2 == 0;
     int order = a->len != b->len ? (a->len < b->len ? -1 : 1) : (a->row < b->row ? -1 : (a->row > b->row ? 1 : 0));
-    return descending ? -order : order;
+    return a->descending ? -order : order;
 }
 
 void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows)
@@ -99,8 +99,18 @@ void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int windo
     OellKey* keys = (OellKey*)malloc((size_t)rowsCount * sizeof(OellKey));
     if (!keys)
         return;
+    const long long longWindow = window > 0 ? (long long)window * SPGPU_OELL_LONG_WINDOW_FACTOR : 0;
+    const unsigned longGroups = longRows > 0 ? (longWindow > 0 ? (unsigned)((rowsCount - 1) / longWindow) + 1u : 1u) : 0u;
     for (int r = 0; r < rowsCount; ++r) {
-        keys[r].group = longRows > 0 && srcRs[r] > longRows ? 0u : 1u + (window > 0 ? (unsigned)(r / window) : 0u);
+        unsigned inClass;
+        if (longRows > 0 && srcRs[r] > longRows) {
+            inClass = longWindow > 0 ? (unsigned)(r / longWindow) : 0u;
+            keys[r].group = inClass;
+        } else {
+            inClass = window > 0 ? (unsigned)(r / window) : 0u;
+            keys[r].group = longGroups + inClass;
+        }
+        keys[r].descending = inClass % 2 == 0;
         keys[r].len = srcRs[r];
         keys[r].row = r;
     }

@@ -106,6 +106,15 @@ template <int POLICY, typename T> __device__ inline T loadX(const T* p)
     }
 }
 
+/* Which deep queue a 32-row sub-group registers in.  A multiplicative hash, not the sub-group number modulo the number
+ * of queues: after an ordering by length the deep sub-groups sit at the heads of the windows, i.e. at multiples of
+ * window / 32, and modulo 1024 all of them would meet in 16 queues (measured: queue overflow and a serial deep kernel). */
+__device__ inline int deepQueueOf(long long subGroup)
+{
+    return (int)(((unsigned)subGroup * 2654435761u) >> (32 - 10)) & (SPGPU_DEEP_QUEUES - 1);
+}
+static_assert(SPGPU_DEEP_QUEUES == 1024, "deepQueueOf keeps 10 bits");
+
 /* Function-scope LDS: only kernels that call this allocate it (the forms without a tile keep 0 bytes of LDS). */
 template <typename E, int N> __device__ inline E* ldsArray()
 {
@@ -309,9 +318,8 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
         }
         int slot = -1;
         if (lane % SUB == 0 && subDepth > a.deepCap) {
-            /* queue = the workgroup of deepSpmvKernel that will finish this sub-group: consecutive sub-groups (the
-             * deepest ones, after an ordering by length) go to consecutive workgroups */
-            const int queue = (int)((row0 >> 5) % SPGPU_DEEP_QUEUES);
+            /* queue = the workgroup of deepSpmvKernel that will finish this sub-group */
+            const int queue = deepQueueOf(row0 >> 5);
             const int at = atomicAdd(&a.deepCounts[queue], 1);
             if (at < SPGPU_DEEP_QUEUE_ENTRIES) {
                 slot = queue * SPGPU_DEEP_QUEUE_ENTRIES + at;

@@ -4,8 +4,9 @@
  * and no long-row group, exactly the reference's: (length, row) descending.
  *
  * Pass 1: one 64-bit key per row, (~length << 32) | ~row, sorted ascending = (length, row) descending.
- * Pass 2 (windows or a long-row group only): a STABLE sort of the pass-1 sequence by group number, which leaves
- *         every group in pass-1 order; the groups that ascend are then read back to front.
+ * Pass 2 (windows or long rows set aside only): a STABLE sort of the pass-1 sequence by group number (the long rows'
+ *         windows first, then the others'), which leaves every group in pass-1 order; the groups that ascend are then
+ *         read back to front.
  * Both sorts are rocPRIM radix sorts; this is format construction, not the SpMV path.
  *
  * Scratch layout:  A [rows u64] | B [rows u64] | rocPRIM temp.   Pass 2 reuses A as {group in, row in} and B as
@@ -15,6 +16,7 @@
 #include "spgpu_internal.h"
 
 #include "spgpu/oell_device.h"
+#include "spgpu/ell_conv.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -45,11 +47,18 @@ static hipError_t orderTempBytes(size_t n, size_t* bytes)
     return hipSuccess;
 }
 
-__device__ inline unsigned groupOfRow(int row, int len, int window, int longRows)
+/* group number with the direction of the group in bit 0: (group << 1) | ascending */
+__device__ inline unsigned groupOfRow(int row, int len, int window, int longRows, unsigned longGroups)
 {
-    if (longRows > 0 && len > longRows)
-        return 0u;
-    return 1u + (window > 0 ? (unsigned)row / (unsigned)window : 0u);
+    unsigned inClass, group;
+    if (longRows > 0 && len > longRows) {
+        inClass = window > 0 ? (unsigned)((long long)row / ((long long)window * SPGPU_OELL_LONG_WINDOW_FACTOR)) : 0u;
+        group = inClass;
+    } else {
+        inClass = window > 0 ? (unsigned)row / (unsigned)window : 0u;
+        group = longGroups + inClass;
+    }
+    return (group << 1) | (inClass & 1u);
 }
 
 __global__ __launch_bounds__(kOeThreads) void lengthKeysKernel(LenKey* keys, const int* rs, int rows)
@@ -60,14 +69,14 @@ __global__ __launch_bounds__(kOeThreads) void lengthKeysKernel(LenKey* keys, con
 }
 
 __global__ __launch_bounds__(kOeThreads) void groupKeysKernel(unsigned* groups, unsigned* rowsOut, const LenKey* sorted,
-                                                              int rows, int window, int longRows)
+                                                              int rows, int window, int longRows, unsigned longGroups)
 {
     const long long stride = (long long)gridDim.x * kOeThreads;
     for (long long i = (long long)blockIdx.x * kOeThreads + threadIdx.x; i < rows; i += stride) {
         const LenKey key = sorted[i];
         const unsigned row = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
         const unsigned len = 0xFFFFFFFFu - (unsigned)(key >> 32);
-        groups[i] = groupOfRow((int)row, (int)len, window, longRows);
+        groups[i] = groupOfRow((int)row, (int)len, window, longRows, longGroups);
         rowsOut[i] = row;
     }
 }
@@ -103,9 +112,9 @@ __global__ __launch_bounds__(kOeThreads) void finishGroupedKernel(int* rIdx, int
 {
     const long long stride = (long long)gridDim.x * kOeThreads;
     for (long long i = (long long)blockIdx.x * kOeThreads + threadIdx.x; i < rows; i += stride) {
-        const unsigned g = sortedGroups[i];
+        const unsigned g = sortedGroups[i]; /* (group << 1) | ascending */
         long long from = i;
-        if (g != 0u && ((g - 1u) & 1u)) { /* an ascending group: its descending run read back to front */
+        if (g & 1u) { /* an ascending group: its descending run read back to front */
             const long long first = firstNotBelow(sortedGroups, rows, g);
             const long long end = firstNotBelow(sortedGroups, rows, g + 1u);
             from = first + (end - 1 - i);
@@ -150,14 +159,16 @@ static spgpuStatus_t orderRows(spgpuHandle_t handle, int* rIdx, int* dstRs, cons
     }
     unsigned* groupIn = reinterpret_cast<unsigned*>(a);
     unsigned* rowIn = groupIn + rows;
+    const long long longWindow = window > 0 ? (long long)window * SPGPU_OELL_LONG_WINDOW_FACTOR : 0;
+    const unsigned longGroups = longRows > 0 ? (longWindow > 0 ? (unsigned)((rows - 1) / longWindow) + 1u : 1u) : 0u;
     hipLaunchKernelGGL(groupKeysKernel, dim3(gridOverOe(rows)), dim3(kOeThreads), 0, s, groupIn, rowIn, (const LenKey*)b, rows,
-                       window, longRows);
+                       window, longRows, longGroups);
     /* b is free again once groupKeysKernel has read it (same stream) */
     unsigned* groupOut = reinterpret_cast<unsigned*>(b);
     unsigned* rowOut = groupOut + rows;
-    const unsigned groups = 2u + (window > 0 ? (unsigned)(rows - 1) / (unsigned)window : 0u);
-    unsigned bits = 1;
-    while (bits < 32 && (1u << bits) < groups)
+    const unsigned groups = longGroups + 1u + (window > 0 ? (unsigned)(rows - 1) / (unsigned)window : 0u);
+    unsigned bits = 2; /* the key is (group << 1) | direction */
+    while (bits < 32 && (1u << bits) < 2u * groups)
         ++bits;
     bytes = tempBytes;
     if (rocprim::radix_sort_pairs(temp, bytes, groupIn, groupOut, rowIn, rowOut, (size_t)rows, 0, bits, s) != hipSuccess)

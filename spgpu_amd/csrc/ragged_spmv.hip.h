@@ -102,7 +102,7 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
         if constexpr (DEEP) {
             if ((lane & 31) == 0 && depth > a.deepCap && i < ROWS) {
                 const long long sub0 = (blockRow0 + i) >> 5;
-                const int queue = (int)(sub0 % SPGPU_DEEP_QUEUES);
+                const int queue = deepQueueOf(sub0);
                 const int at = atomicAdd(&a.deepCounts[queue], 1);
                 if (at < SPGPU_DEEP_QUEUE_ENTRIES) {
                     slot = queue * SPGPU_DEEP_QUEUE_ENTRIES + at;

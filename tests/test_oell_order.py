@@ -9,24 +9,23 @@ from spgpu_amd import formats, synth
 
 
 def brute_order(lengths, window, long_rows):
-    """The definition, spelt out: groups in ascending number; (length, row) descending in group 0 and in every other
-    window from the first, ascending in the windows in between."""
+    """The definition, spelt out: the long rows first, in windows 32 times as large, then the others in their windows;
+    (length, row) descending in the first window of a class and in every other one from there, ascending in between."""
     lengths = np.asarray(lengths)
     n = lengths.size
     out = []
-    pool = [r for r in range(n) if long_rows > 0 and lengths[r] > long_rows]
-    out += sorted(pool, key=lambda r: (-lengths[r], -r))
-    rest = [r for r in range(n) if not (long_rows > 0 and lengths[r] > long_rows)]
-    w = window if window > 0 else max(n, 1)
-    for g in range((n + w - 1) // w):
-        rows = [r for r in rest if r // w == g]
-        key = (lambda r: (-lengths[r], -r)) if g % 2 == 0 else (lambda r: (lengths[r], r))
-        out += sorted(rows, key=key)
+    is_long = [long_rows > 0 and lengths[r] > long_rows for r in range(n)]
+    for rows, w in (([r for r in range(n) if is_long[r]], 32 * window if window > 0 else max(n, 1)),
+                    ([r for r in range(n) if not is_long[r]], window if window > 0 else max(n, 1))):
+        for g in range((n + w - 1) // w):
+            members = [r for r in rows if r // w == g]
+            key = (lambda r: (-lengths[r], -r)) if g % 2 == 0 else (lambda r: (lengths[r], r))
+            out += sorted(members, key=key)
     return np.array(out, np.int32)
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 257, 1000])
-@pytest.mark.parametrize("window,long_rows", [(0, 0), (8, 0), (64, 0), (0, 5), (16, 5), (100, 12), (5000, 0)])
+@pytest.mark.parametrize("window,long_rows", [(0, 0), (8, 0), (64, 0), (0, 5), (16, 5), (2, 3), (100, 12), (5000, 0)])
 def test_order_matches_its_definition(n, window, long_rows):
     rng = np.random.default_rng(n * 131 + window * 7 + long_rows)
     lengths = np.minimum(rng.zipf(1.7, size=n), 40).astype(np.int32)

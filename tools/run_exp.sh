@@ -1,6 +1,5 @@
 cd /root/repo
-timeout -k 10 600 python -m pytest tests/test_gpu_oell_device.py -x -q -k "ragged or deep" 2>&1 | tail -2
-EXP_FORMS=ragged0,ragged1 timeout -k 10 300 python tools/exp_tile.py D 10000000 mild 2>&1 | grep "^D " | grep -v plain
-EXP_PATTERNS=near EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256,4096:256 EXP_FORMS=ragged0,ragged1 timeout -k 10 300 python tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep "^D "
-export SPGPU_LIB=/root/repo/spgpu_amd/lib_ab/libspgpu_trace.so
-timeout -k 10 300 python tools/exp_trace.py 10000000 2048:256 powerlaw 2>&1 | grep -v "amdgpu.ids\|t = "
+timeout -k 10 600 python -m pytest tests/test_gpu_oell_device.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -2
+for cap in 256 128; do
+EXP_PATTERNS=near EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256,4096:256 EXP_FORMS=ragged0,ragged1 SPGPU_DEEP_CAP=$cap timeout -k 10 300 python tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep "^D " | sed "s/^/cap $cap /"
+done
