@@ -14,11 +14,10 @@
  * synchronise that stream.  `work` is caller-provided scratch of
  * spgpuCooConvertWorkBytes(rows, nnz) bytes.
  *
- * Method: row lengths by atomic histogram; exclusive scan; entries bucketed per
- * row with an atomic cursor (arbitrary order inside a row); the position k of an
- * entry inside its row is then recomputed as the number of entries of the same
- * row with a smaller COO index (an exact, order-independent count), which
- * restores the reference's encounter order without a sort.
+ * Method: ONE stable radix sort of (row, entry id) pairs groups the entries by row in encounter order (rocPRIM;
+ * format construction, not the SpMV path); row starts by binary search in the sorted rows; an entry's position k
+ * inside its row is its sorted position minus the row's start.  No atomics: the arrays do not depend on scheduling,
+ * and a row of any length costs what its entries cost.
  */
 #include "core.h"
 
@@ -26,7 +25,7 @@
 extern "C" {
 #endif
 
-/* Bytes of scratch the conversions below need. */
+/* Bytes of scratch the conversions below need (about 16 bytes per nonzero; 0 if no GPU can be asked for rocPRIM's share). */
 size_t spgpuCooConvertWorkBytes(int rowsCount, int nonZerosCount);
 
 /* Pass 1 (device counterpart of computeEllRowLenghts, ell.c:5-31): fills rowLengths[rowsCount] on the device,

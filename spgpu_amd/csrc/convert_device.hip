@@ -3,17 +3,24 @@
  * New functionality; the arrays it produces are byte-identical to the host
  * converters' (spgpu_amd/csrc/conv_ell.c, conv_hell.c; reference ell.c:5-80, hell.c:4-104).
  *
- * Scratch layout (ints):  misc[16] | rowStart[rows+1] | cursor[rows] | scanTotals[tiles+2] | bucket[nnz]
- *   rowStart  exclusive scan of the row lengths
- *   bucket    COO entry ids grouped by row (order inside a row arbitrary: filled with an atomic cursor)
- *   misc[0]   longest row / total slots, misc[1] out-of-range flag
- * The k-th position of entry e inside its row is #{e' in the row's bucket : e' < e}: exact whatever order
- * the atomics produced, so the result does not depend on scheduling.
+ * Scratch layout (ints):  misc[16] | rowStart[rows+1] | depth[rows] | scanTotals[tiles+2] | rowOf[nnz] | entry[nnz] | rocPRIM temp
+ *   entry     COO entry ids sorted by row, ascending inside a row: ONE stable radix sort of (row, entry id) pairs
+ *             (rocPRIM; keys through a transform iterator, ids from a counting iterator, so no input copy is made)
+ *   rowOf     the sorted row numbers; an entry outside [0, rows) gets the key `rows` and sorts behind all rows
+ *   rowStart  rowStart[r] = first position whose row is >= r (binary search in rowOf); rowStart[rows] = valid entries
+ *   misc[0]   longest row, misc[1] out-of-range flag
+ * The k-th position of the entry at sorted position p is p - rowStart[row]: the reference's encounter order, with no
+ * atomics anywhere (round 1 bucketed with an atomic cursor and recovered k by counting smaller ids in the bucket --
+ * quadratic in the row length, minutes for a row of 10^5 entries).
  */
 #include "numeric.hip.h"
 #include "spgpu_internal.h"
 
 #include "spgpu/convert_device.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace spgpu {
 
@@ -23,17 +30,41 @@ constexpr int kScanTile = kCvThreads * kScanPerThread;
 
 struct ConvertWork {
     int* rowStart;
-    int* cursor;
-    int* bucket;
+    int* cursor; /* per-hack depths of the HELL plan */
     int* scanTotals;
     int* misc;
+    unsigned* rowOf;
+    int* bucket; /* entry ids sorted by row */
+    void* temp;
 };
 
 static size_t scanBlocks(long long n) { return (size_t)((n + kScanTile - 1) / kScanTile); }
+static size_t alignUpCv(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* zero-based row of a COO entry as the sort key; anything outside the matrix becomes `rows` */
+struct RowKeyOf {
+    int base, rows;
+    __host__ __device__ unsigned operator()(int stored) const
+    {
+        const unsigned r = (unsigned)(stored - base);
+        return r < (unsigned)rows ? r : (unsigned)rows;
+    }
+};
+typedef rocprim::transform_iterator<const int*, RowKeyOf, unsigned> RowKeyIterator;
+
+static hipError_t sortTempBytes(size_t nnz, size_t* bytes)
+{
+    size_t need = 0;
+    const hipError_t err = rocprim::radix_sort_pairs(nullptr, need, RowKeyIterator((const int*)nullptr, RowKeyOf{0, 1}), (unsigned*)nullptr,
+                                                     rocprim::counting_iterator<int>(0), (int*)nullptr, nnz);
+    *bytes = alignUpCv(need, 256);
+    return err;
+}
+
+static size_t fixedInts(int rows) { return alignUpCv((size_t)16 + 2 * (size_t)rows + 1 + scanBlocks((long long)rows + 1) + 2, 64); }
 
 static ConvertWork carve(void* work, int rows, int nnz)
 {
-    (void)nnz; /* the bucket comes last, so every other area has a position that depends on rows only */
     ConvertWork w;
     int* p = static_cast<int*>(work);
     w.misc = p;
@@ -43,8 +74,12 @@ static ConvertWork carve(void* work, int rows, int nnz)
     w.cursor = p;
     p += (size_t)rows;
     w.scanTotals = p;
-    p += scanBlocks((long long)rows + 1) + 2;
+    p = static_cast<int*>(work) + fixedInts(rows); /* what follows depends on nnz; the HELL plan only uses what precedes */
+    w.rowOf = reinterpret_cast<unsigned*>(p);
+    p += alignUpCv((size_t)(nnz > 0 ? nnz : 0), 64);
     w.bucket = p;
+    p += alignUpCv((size_t)(nnz > 0 ? nnz : 0), 64);
+    w.temp = p;
     return w;
 }
 
@@ -54,17 +89,30 @@ static unsigned gridFor(long long n)
     return (unsigned)(blocks < 1 ? 1 : (blocks > 1048576 ? 1048576 : blocks));
 }
 
-__global__ __launch_bounds__(kCvThreads) void histogramKernel(int* rowLengths, int rows, int nnz, const int* cooRows,
-                                                              int base, int* misc)
+/* rowStart[r] = first sorted position whose row is >= r, r = 0 .. rows */
+__global__ __launch_bounds__(kCvThreads) void rowStartKernel(int* rowStart, int rows, const unsigned* rowOf, int nnz)
 {
     const long long stride = (long long)gridDim.x * kCvThreads;
-    for (long long e = (long long)blockIdx.x * kCvThreads + threadIdx.x; e < nnz; e += stride) {
-        const int r = cooRows[e] - base;
-        if (r < 0 || r >= rows)
-            misc[1] = 1; /* out-of-range row: reported to the host, entry skipped */
-        else
-            atomicAdd(&rowLengths[r], 1);
+    for (long long r = (long long)blockIdx.x * kCvThreads + threadIdx.x; r <= rows; r += stride) {
+        int lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int mid = lo + ((hi - lo) >> 1);
+            if (rowOf[mid] < (unsigned)r)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        rowStart[r] = lo;
     }
+}
+
+__global__ __launch_bounds__(kCvThreads) void rowLengthsKernel(int* rowLengths, const int* rowStart, int rows, int nnz, int* misc)
+{
+    const long long stride = (long long)gridDim.x * kCvThreads;
+    for (long long r = (long long)blockIdx.x * kCvThreads + threadIdx.x; r < rows; r += stride)
+        rowLengths[r] = rowStart[r + 1] - rowStart[r];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && rowStart[rows] < nnz)
+        misc[1] = 1; /* entries outside the matrix: reported to the host, the entries skipped */
 }
 
 __global__ __launch_bounds__(kCvThreads) void maxKernel(const int* values, long long n, int scale, int* misc)
@@ -165,17 +213,6 @@ static void exclusiveScan(hipStream_t s, int* out, const int* in, long long n, i
     hipLaunchKernelGGL(addTotalsKernel, dim3((unsigned)tiles), dim3(kCvThreads), 0, s, out, n, totals);
 }
 
-__global__ __launch_bounds__(kCvThreads) void bucketKernel(int* bucket, int* cursor, const int* rowStart, int rows, int nnz,
-                                                           const int* cooRows, int base)
-{
-    const long long stride = (long long)gridDim.x * kCvThreads;
-    for (long long e = (long long)blockIdx.x * kCvThreads + threadIdx.x; e < nnz; e += stride) {
-        const int r = cooRows[e] - base;
-        if (r >= 0 && r < rows)
-            bucket[rowStart[r] + atomicAdd(&cursor[r], 1)] = (int)e;
-    }
-}
-
 /* Longest row of every hack (hell.c:71-88). */
 __global__ __launch_bounds__(kCvThreads) void hackDepthKernel(int* depth, int hacks, int hackSize, int rows, const int* rowLengths)
 {
@@ -192,22 +229,19 @@ __global__ __launch_bounds__(kCvThreads) void hackDepthKernel(int* depth, int ha
     depth[h] = longest;
 }
 
-/* One thread per bucket position: recover k = rank of the entry inside its row, then place it. */
+/* One thread per sorted position: the entry, its row, and its place inside the row. */
 template <typename ELEM, bool TO_HELL>
 __global__ __launch_bounds__(kCvThreads) void placeKernel(ELEM* values, int* indices, long long valStride, long long idxStride,
                                                           const int* hackOffsets, int hackSize, int outBase, int rows,
-                                                          int nnz, const int* cooRows, const int* cooCols, const ELEM* cooVals,
-                                                          int cooBase, const int* rowStart, const int* bucket)
+                                                          int nnz, const int* cooCols, const ELEM* cooVals, int cooBase,
+                                                          const int* rowStart, const unsigned* rowOf, const int* bucket)
 {
     const long long stride = (long long)gridDim.x * kCvThreads;
-    for (long long p = (long long)blockIdx.x * kCvThreads + threadIdx.x; p < nnz; p += stride) {
-        if (p >= rowStart[rows])
-            continue; /* entries with out-of-range rows were never bucketed */
+    const int valid = rowStart[rows];
+    for (long long p = (long long)blockIdx.x * kCvThreads + threadIdx.x; p < valid; p += stride) {
         const int e = bucket[p];
-        const int r = cooRows[e] - cooBase;
-        int k = 0;
-        for (int q = rowStart[r]; q < rowStart[r + 1]; ++q)
-            k += bucket[q] < e;
+        const int r = (int)rowOf[p];
+        const int k = (int)p - rowStart[r];
         long long slot;
         if constexpr (TO_HELL) {
             const int hack = r / hackSize;
@@ -228,6 +262,7 @@ static spgpuStatus_t place(spgpuHandle_t handle, void* values, int* indices, lon
                            const int* hackOffsets, int hackSize, int outBase, int rows, int nnz, const int* cooRows,
                            const int* cooCols, const void* cooVals, int cooBase, spgpuType_t type, const ConvertWork& w)
 {
+    (void)cooRows; /* the sorted row numbers are in the scratch */
     if (nnz <= 0 || rows <= 0)
         return SPGPU_SUCCESS;
     hipStream_t s = handle->currentStream;
@@ -235,18 +270,18 @@ static spgpuStatus_t place(spgpuHandle_t handle, void* values, int* indices, lon
     switch (spgpuSizeOf(type)) {
     case 4:
         hipLaunchKernelGGL((placeKernel<unsigned, TO_HELL>), grid, block, 0, s, static_cast<unsigned*>(values), indices, valStride,
-                           idxStride, hackOffsets, hackSize, outBase, rows, nnz, cooRows, cooCols,
-                           static_cast<const unsigned*>(cooVals), cooBase, w.rowStart, w.bucket);
+                           idxStride, hackOffsets, hackSize, outBase, rows, nnz, cooCols,
+                           static_cast<const unsigned*>(cooVals), cooBase, w.rowStart, w.rowOf, w.bucket);
         break;
     case 8:
         hipLaunchKernelGGL((placeKernel<unsigned long long, TO_HELL>), grid, block, 0, s, static_cast<unsigned long long*>(values),
-                           indices, valStride, idxStride, hackOffsets, hackSize, outBase, rows, nnz, cooRows, cooCols,
-                           static_cast<const unsigned long long*>(cooVals), cooBase, w.rowStart, w.bucket);
+                           indices, valStride, idxStride, hackOffsets, hackSize, outBase, rows, nnz, cooCols,
+                           static_cast<const unsigned long long*>(cooVals), cooBase, w.rowStart, w.rowOf, w.bucket);
         break;
     case 16:
         hipLaunchKernelGGL((placeKernel<Bits128, TO_HELL>), grid, block, 0, s, static_cast<Bits128*>(values), indices, valStride,
-                           idxStride, hackOffsets, hackSize, outBase, rows, nnz, cooRows, cooCols,
-                           static_cast<const Bits128*>(cooVals), cooBase, w.rowStart, w.bucket);
+                           idxStride, hackOffsets, hackSize, outBase, rows, nnz, cooCols,
+                           static_cast<const Bits128*>(cooVals), cooBase, w.rowStart, w.rowOf, w.bucket);
         break;
     default:
         return SPGPU_UNSUPPORTED;
@@ -314,8 +349,12 @@ extern "C" {
 
 size_t spgpuCooConvertWorkBytes(int rowsCount, int nonZerosCount)
 {
-    const size_t rows = rowsCount > 0 ? (size_t)rowsCount : 0, nnz = nonZerosCount > 0 ? (size_t)nonZerosCount : 0;
-    return (16 + 2 * rows + 1 + scanBlocks((long long)rows + 1) + 2 + nnz) * sizeof(int);
+    const int rows = rowsCount > 0 ? rowsCount : 0;
+    const size_t nnz = nonZerosCount > 0 ? (size_t)nonZerosCount : 0;
+    size_t temp = 0;
+    if (nnz > 0 && sortTempBytes(nnz, &temp) != hipSuccess)
+        return 0; /* no GPU to ask for rocPRIM's share */
+    return (fixedInts(rows) + 2 * alignUpCv(nnz, 64)) * sizeof(int) + temp + 256;
 }
 
 spgpuStatus_t spgpuCooRowLengthsDevice(spgpuHandle_t handle, int* rowLengths, int* maxRowSize, int rowsCount,
@@ -326,20 +365,23 @@ spgpuStatus_t spgpuCooRowLengthsDevice(spgpuHandle_t handle, int* rowLengths, in
         return SPGPU_SUCCESS;
     hipStream_t s = handle->currentStream;
     const ConvertWork w = carve(work, rowsCount, nonZerosCount);
-    (void)hipMemsetAsync(rowLengths, 0, (size_t)rowsCount * sizeof(int), s);
-    (void)hipMemsetAsync(w.cursor, 0, (size_t)rowsCount * sizeof(int), s);
     (void)hipMemsetAsync(w.misc, 0, 16 * sizeof(int), s);
-    if (nonZerosCount > 0)
-        hipLaunchKernelGGL(histogramKernel, dim3(gridFor(nonZerosCount)), dim3(kCvThreads), 0, s, rowLengths, rowsCount,
-                           nonZerosCount, cooRowIndices, cooBaseIndex, w.misc);
+    if (nonZerosCount > 0) {
+        size_t bytes = 0;
+        if (sortTempBytes((size_t)nonZerosCount, &bytes) != hipSuccess)
+            return SPGPU_UNSPECIFIED;
+        unsigned bits = 1; /* keys are 0 .. rows */
+        while (bits < 32 && (1u << bits) <= (unsigned)rowsCount)
+            ++bits;
+        if (rocprim::radix_sort_pairs(w.temp, bytes, RowKeyIterator(cooRowIndices, RowKeyOf{cooBaseIndex, rowsCount}), w.rowOf,
+                                      rocprim::counting_iterator<int>(0), w.bucket, (size_t)nonZerosCount, 0, bits, s) != hipSuccess)
+            return SPGPU_UNSPECIFIED;
+    }
+    hipLaunchKernelGGL(rowStartKernel, dim3(gridFor((long long)rowsCount + 1)), dim3(kCvThreads), 0, s, w.rowStart, rowsCount,
+                       (const unsigned*)w.rowOf, nonZerosCount > 0 ? nonZerosCount : 0);
+    hipLaunchKernelGGL(rowLengthsKernel, dim3(gridFor(rowsCount)), dim3(kCvThreads), 0, s, rowLengths, (const int*)w.rowStart,
+                       rowsCount, nonZerosCount > 0 ? nonZerosCount : 0, w.misc);
     hipLaunchKernelGGL(maxKernel, dim3(gridFor(rowsCount)), dim3(kCvThreads), 0, s, rowLengths, (long long)rowsCount, 1, w.misc);
-    /* rowStart[0..rows] = exclusive scan of the lengths (rowStart[rows] = bucketed entries) */
-    (void)hipMemsetAsync(w.rowStart + rowsCount, 0, sizeof(int), s);
-    exclusiveScan(s, w.rowStart, rowLengths, (long long)rowsCount, 1, w.scanTotals);
-    (void)hipMemcpyAsync(w.rowStart + rowsCount, w.scanTotals + scanBlocks(rowsCount), sizeof(int), hipMemcpyDeviceToDevice, s);
-    if (nonZerosCount > 0)
-        hipLaunchKernelGGL(bucketKernel, dim3(gridFor(nonZerosCount)), dim3(kCvThreads), 0, s, w.bucket, w.cursor, w.rowStart,
-                           rowsCount, nonZerosCount, cooRowIndices, cooBaseIndex);
     int* host = static_cast<int*>(spgpuPrivate(handle)->reduceHost);
     (void)hipMemcpyAsync(host, w.misc, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);

@@ -237,3 +237,24 @@ def test_device_coo_to_dia_matches_host(gpu, letter):
     work = torch.empty(capi.spgpuCooDiaWorkBytes(5, 5), dtype=torch.uint8, device="cuda:0")
     count = C.c_int(-1)
     assert capi.spgpuCooDiaPlanDevice(gpu, C.byref(count), 5, 5, 2, _p(bad), _p(bad), 0, _p(work)) == capi.SPGPU_UNSUPPORTED
+
+
+def test_one_row_of_300k_entries(gpu):
+    """A row far longer than anything a hack of 32 was made for (a hub of a power-law graph): 300 000 entries in one row
+    among 5 000 ordinary rows, COO order shuffled.  The position of an entry inside its row is its sorted position minus
+    the row's start -- cost linear in the entries (round 1 recounted it by scanning the row's bucket: 9e10 steps here)."""
+    from spgpu_amd import formats
+    rng = np.random.default_rng(4)
+    n_rows, hub = 5000, 1234
+    lengths = rng.integers(0, 9, size=n_rows)
+    lengths[hub] = 300_000
+    r = np.repeat(np.arange(n_rows), lengths)
+    c = rng.integers(0, 400_000, size=r.size)
+    v = rng.standard_normal(r.size)
+    order = rng.permutation(r.size)
+    r, c, v = r[order], c[order], v[order]
+    ell_h = formats.coo_to_ell(n_rows, r, c, v)
+    hell_h = formats.ell_to_hell(ell_h, 32)
+    ell_d, hell_d = _device_convert(gpu, n_rows, r, c, v, 0, 32)
+    _same(ell_d, ell_h, ("max_row", "pitch", "row_lengths", "indices", "values"))
+    _same(hell_d, hell_h, ("height", "hack_offsets", "indices", "values"))
