@@ -312,6 +312,10 @@ def bench_c1(handle, stream, dev):
                     out["cg_graph_us_per_iteration"] = float(words[words.index("us") - 1])
                     out["cg_eager_host_scalars_us_per_iteration"] = float(words[words.index("scalars:") + 1])
                     out["cg_iterates"] = line.split("; iterate")[-1].strip()
+                if line.startswith("fused replay:"):
+                    words = line.replace("(", " ").split()
+                    out["cg_fused_graph_us_per_iteration"] = float(words[words.index("us") - 1])
+                    out["cg_fused_iterates"] = line.split("; iterate")[-1].strip()
         except (OSError, subprocess.SubprocessError, ValueError) as error:
             out["cg"] = f"not run: {error!r}"
     return out

@@ -239,6 +239,13 @@ for _L in "SD":
     axpby_device[_L] = _decl(f"spgpu{_L}axpbyDevice", None, [Handle, ptr, i32, ptr, ptr, ptr, ptr])
     axpby_quot_device[_L] = _decl(f"spgpu{_L}axpbyQuotDevice", None, [Handle, ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, ptr])
     div_device[_L] = _decl(f"spgpu{_L}divDevice", None, [Handle, ptr, ptr, ptr, i32])
+hellspmv_dot_device, axpby_pair_dot_device = {}, {}
+for _L in "SD":
+    _S = SCALAR[_L]
+    hellspmv_dot_device[_L] = _decl(f"spgpu{_L}hellspmvDotDevice", None,
+                                    [Handle, ptr, ptr, ptr, ptr, _S, ptr, ptr, i32, ptr, ptr, i32, ptr, _S, i32])
+    axpby_pair_dot_device[_L] = _decl(f"spgpu{_L}axpbyPairDotDevice", None,
+                                      [Handle, ptr, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr])
 
 
 # ---- tuning.h: per-handle kernel-form hint ---------------------------------------------------------------------

@@ -13,15 +13,14 @@
  * for a whole multivector (grid.y = vector index).
  * dot / nrm2 are two-stage: every workgroup reduces a grid-stride slice with
  * lane-xor shuffles and one LDS hop between its 4 wavefronts, writes one
- * partial into scratch owned by the HANDLE, and the host adds the partials in
- * block order after one async copy + stream sync (the reference copies from a
+ * partial into scratch owned by the HANDLE, and the host combines the partials (reduce.hip.h:
+ * finalOrder) after one async copy + stream sync (the reference copies from a
  * process-global __device__ array, kernels/ddot.cu:35,139).
  *
  * Roofline: HBM.  Algorithmic bytes: axpby n*sizeof(T)*(2 + [beta != 0]);
  * dot 2*n*sizeof(T); nrm2 n*sizeof(T).
  */
-#include "numeric.hip.h"
-#include "spgpu_internal.h"
+#include "reduce.hip.h"
 
 #include "spgpu/vector.h"
 #include "spgpu/device_scalars.h"
@@ -33,7 +32,6 @@
 
 namespace spgpu {
 
-constexpr int kL1Threads = 256;
 constexpr int kL1MaxBlocksDefault = 16384; /* measured: 2 048 -> 64.7 %, 16 384 -> 71 % of 8 TB/s for axpby (tile-stride loop beyond) */
 static int l1MaxBlocks()
 {
@@ -50,7 +48,6 @@ __device__ inline double axpbyOne(double alpha, double x, double beta, double y)
 __device__ inline cfloat axpbyOne(cfloat alpha, cfloat x, cfloat beta, cfloat y) { return mulAdd(beta, y, mul(alpha, x)); }
 __device__ inline cdouble axpbyOne(cdouble alpha, cdouble x, cdouble beta, cdouble y) { return mulAdd(alpha, x, mul(beta, y)); }
 
-constexpr int kL1Unroll = 4; /* independent 16-byte accesses in flight per lane */
 
 template <typename T, int VEC, bool HAS_BETA, bool NT = false>
 __device__ inline void axpbyBody(T* z, int n, T beta, const T* y, T alpha, const T* x, long long pitch)
@@ -109,14 +106,6 @@ __global__ __launch_bounds__(kL1Threads) void axpbyKernel(T* z, int n, T beta, c
 
 /* scalars from device memory (include/spgpu/device_scalars.h): the same two bodies, chosen by the value of beta.
  * A coefficient is num/den (NULL = 1); hasBeta == 0: no y at all. */
-template <typename T> __device__ inline T quotientAt(const T* num, const T* den)
-{
-    if (num && den)
-        return *num / *den;
-    if (num)
-        return *num;
-    return den ? T(1) / *den : T(1);
-}
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(kL1Threads) void axpbyDeviceKernel(T* z, int n, int hasBeta, const T* betaNum, const T* betaDen,
@@ -199,7 +188,6 @@ static void axpbyLaunch(spgpuHandle_t handle, ApiT* zApi, int n, ApiT betaApi, A
 /* DOT : a[i]*b[i] accumulated with the SpMV multiply-add (un-conjugated, zdot.cu:54)
  * NRM2: |a[i]|^2 accumulated in the real type (dnrm2.cu:52-53)
  * ASUM: |a[i]| added; AMAX: max |a[i]|  (|.| of a complex value as cuCabs) */
-enum ReduceMode { kDot = 0, kNrm2 = 1, kAsum = 2, kAmax = 3 };
 
 template <typename T> struct RealOf { using type = T; };
 template <typename R> struct RealOf<Cx<R>> { using type = R; };
@@ -221,29 +209,6 @@ template <typename R> __device__ inline R magnitude(Cx<R> z)
     return (v == R(0) || v > huge || w > huge) ? v + w : t;
 }
 
-template <int MODE, typename A> __device__ __host__ inline A combine(A x, A y)
-{
-    if constexpr (MODE == kAmax)
-        return y > x ? y : x;
-    else
-        return add(x, y);
-}
-
-template <int MODE, typename A> __device__ inline A blockCombine(A v, A* lds)
-{
-#pragma unroll
-    for (int m = 1; m < kWave; m <<= 1)
-        v = combine<MODE>(v, laneXor(v, m));
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & (kWave - 1)) == 0)
-        lds[wave] = v;
-    __syncthreads();
-    A total = lds[0];
-#pragma unroll
-    for (int w = 1; w < kL1Threads / kWave; ++w)
-        total = combine<MODE>(total, lds[w]);
-    return total;
-}
 
 /* What a reduction returns when the device could not deliver its partials. */
 template <typename A> static inline A notANumber();
@@ -374,47 +339,12 @@ static void reduceVectors(spgpuHandle_t handle, typename AccOf<T, MODE>::type* o
         }
 
         for (int j = 0; j < vectors; ++j) {
-            Acc total = zeroOf<Acc>();
-            for (long long k = 0; k < blocks; ++k)
-                total = combine<MODE>(total, host[(size_t)j * blocks + k]);
-            out[first + j] = total;
+            out[first + j] = finalOrder<MODE>(host + (size_t)j * blocks, blocks);
         }
     }
     spgpuDebugCheck(handle, "reduction");
 }
 
-/* Second stage on the device (device_scalars.h): the block partials are added in block order -- the order, and so the
- * bits, of reduceVectors' host loop.  That is ONE dependent chain of additions; the workgroup first copies the
- * partials to LDS (parallel loads), then lane 0 runs the chain with the operands of the next 16 steps already on
- * their way from LDS.  (Finalising inside reduceKernel by the workgroup that arrives last was measured slower:
- * every workgroup then pays a device-scope fence, 16.6 us against 5.0 + 3 us per dot of 2^20 doubles.) */
-template <typename Acc, int MODE>
-__global__ __launch_bounds__(kL1Threads) void reduceFinalKernel(Acc* result, const Acc* partials, int blocks)
-{
-    constexpr int STEP = 16;
-    __shared__ Acc all[SPGPU_REDUCE_MAX_BLOCKS + 2 * STEP];
-    for (int k = threadIdx.x; k < SPGPU_REDUCE_MAX_BLOCKS + 2 * STEP; k += kL1Threads)
-        all[k] = k < blocks ? partials[k] : zeroOf<Acc>(); /* + 0 changes nothing: the chain starts at +0 */
-    __syncthreads();
-    if (threadIdx.x != 0)
-        return;
-    Acc sum = zeroOf<Acc>(), now[STEP], next[STEP];
-#pragma unroll
-    for (int u = 0; u < STEP; ++u)
-        now[u] = all[u];
-    for (int k0 = 0; k0 < blocks; k0 += STEP) {
-#pragma unroll
-        for (int u = 0; u < STEP; ++u)
-            next[u] = all[k0 + STEP + u];
-#pragma unroll
-        for (int u = 0; u < STEP; ++u)
-            sum = combine<MODE>(sum, now[u]);
-#pragma unroll
-        for (int u = 0; u < STEP; ++u)
-            now[u] = next[u];
-    }
-    *result = sum;
-}
 
 /* dot with the result left in device memory: same first stage and same grid as reduceVectors for one vector;
  * no copy, no synchronisation (capturable in a graph). */
@@ -437,7 +367,7 @@ static void dotToDevice(spgpuHandle_t handle, T* result, int n, const T* a, cons
         else
             hipLaunchKernelGGL((reduceKernel<T, 1, kDot>), grid, dim3(kL1Threads), 0, s, dev, n, a, b, 0ll);
     }
-    hipLaunchKernelGGL((reduceFinalKernel<T, kDot>), dim3(1), dim3(kL1Threads), 0, s, result, dev, (int)blocks);
+    hipLaunchKernelGGL((reduceFinalKernel<T, kDot>), dim3(1), dim3(kWave), 0, s, result, dev, (int)blocks);
     spgpuDebugCheck(handle, "dotDevice");
 }
 

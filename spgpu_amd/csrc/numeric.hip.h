@@ -122,6 +122,16 @@ template <typename E, int N> __device__ inline void storePack(E* p, const Pack<E
     *reinterpret_cast<Raw*>(p) = raw;
 }
 
+/* The store counterpart of loadPackElementAligned. */
+template <typename E, int N> __device__ inline void storePackElementAligned(E* p, const Pack<E, N>& value)
+{
+    using Raw = typename RawBits<sizeof(E) * N>::type;
+    typedef Raw LooseRaw __attribute__((aligned(alignof(E))));
+    Raw raw;
+    __builtin_memcpy(&raw, &value, sizeof(raw));
+    *reinterpret_cast<LooseRaw*>(p) = raw;
+}
+
 template <bool NT, typename E, int N> __device__ inline void storePackMaybeNT(E* p, const Pack<E, N>& value)
 {
     using Raw = typename RawBits<sizeof(E) * N>::type;

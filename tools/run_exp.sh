@@ -1,4 +1,3 @@
 cd /root/repo
-SPGPU_RAGGED=2 timeout -k 10 600 python -m pytest tests/test_gpu_oell_device.py -x -q -k "ragged" 2>&1 | tail -2
-EXP_PATTERNS=near EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256,4096:256 EXP_FORMS=ragged0,raggedp0,raggedp1 timeout -k 10 300 python tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep "^D "
-EXP_FORMS=ragged0,raggedp0,raggedp1 timeout -k 10 300 python tools/exp_tile.py D 10000000 mild 2>&1 | grep "^D " | grep -v plain
+timeout -k 10 600 python -m pytest tests/test_gpu_fused_solver.py tests/test_gpu_device_scalars.py tests/test_gpu_level1.py -x -q 2>&1 | tail -4 &&
+timeout -k 10 120 ./tools/cg_amd.bin 1024 60 1e-30 2>&1 | tail -4
