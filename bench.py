@@ -228,7 +228,9 @@ def check_windows(h, x, z, letter, shape, windows=3, rows=2048):
 def bench_powerlaw(args, handle, stream, dev, rows):
     """The north_star target: HELL fp64 on power-law row lengths (mean 32, max 2048), as the rows come and after the
     device-side ordering by length (spgpuOellOrderDevice: windows of 2048 rows, rows longer than 256 set aside; the
-    COO route through spgpuCooToHellDevice), columns near the row (+-2048, not consecutive) and scattered."""
+    COO route through spgpuCooToHellDevice); columns near the row (+-2048, not consecutive: every row, however short,
+    spreads over 4 096 columns), as a band (consecutive columns centred on the row, configs[1]'s pattern with the
+    row's own length) and scattered."""
     import torch
     import oracle_api as O
     from spgpu_amd import capi, formats, synth
@@ -239,10 +241,10 @@ def bench_powerlaw(args, handle, stream, dev, rows):
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     out = dict(rows=rows, mean_len=round(float(lengths.mean()), 2), max_len=int(lengths.max()),
                order="spgpuOellOrderDevice(window=2048, longRows=256) + spgpuCooPermuteRowsDevice + spgpuCooToHellDevice")
-    for pattern in ("near", "random"):
+    for pattern in ("near", "band", "random"):
         coo = synth.ragged_coo_on_device(lengths, rows, pattern, 2048, letter, seed=5, device=dev)
         torch.cuda.synchronize()
-        for name, ordered in (("plain", False), ("sorted", True)):
+        for name, ordered in ((("sorted", True),) if pattern == "band" else (("plain", False), ("sorted", True))):
             t0 = time.perf_counter()
             h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, 2048, 256, order=ordered)
             build_s = time.perf_counter() - t0

@@ -157,22 +157,24 @@ int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows)
     return slot;
 }
 
-/* ---- deep queues of the ELL/HELL SpMV (spgpu_internal.h) ---- */
-spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, int** counts, SpgpuDeepEntry** entries, void** partials)
+/* ---- deep list of the ELL/HELL SpMV (spgpu_internal.h) ---- */
+spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, SpgpuDeepList* list)
 {
     SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
-    const size_t slots = (size_t)SPGPU_DEEP_QUEUES * SPGPU_DEEP_QUEUE_ENTRIES;
-    const size_t countBytes = (size_t)SPGPU_DEEP_QUEUES * sizeof(int);
+    const size_t headBytes = SPGPU_DEEP_HEAD_INTS * sizeof(int);
+    const size_t entryBytes = (size_t)SPGPU_DEEP_ENTRIES * sizeof(SpgpuDeepEntry);
+    const size_t itemEntryBytes = (size_t)SPGPU_DEEP_ITEMS * sizeof(int);
+    const size_t partialBytes = (size_t)SPGPU_DEEP_ENTRIES * 32 * 16;
+    const size_t itemSumBytes = (size_t)SPGPU_DEEP_ITEMS * 32 * 16;
     pthread_mutex_lock(&h->formLock);
     if (!h->deepScratch) {
         /* first use: one allocation and one blocking memset (not capturable in a graph: warm the handle up first) */
-        const size_t bytes = countBytes + slots * (sizeof(SpgpuDeepEntry) + 32 * 16);
         int previous = 0;
         hipGetDevice(&previous);
         hipSetDevice(h->pub.device);
         void* p = NULL;
-        if (hipMalloc(&p, bytes) == hipSuccess) {
-            if (hipMemset(p, 0, countBytes) == hipSuccess)
+        if (hipMalloc(&p, headBytes + entryBytes + itemEntryBytes + partialBytes + itemSumBytes) == hipSuccess) {
+            if (hipMemset(p, 0, headBytes + entryBytes + itemEntryBytes) == hipSuccess)
                 h->deepScratch = p;
             else
                 hipFree(p);
@@ -183,9 +185,11 @@ spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, int** counts, SpgpuDeepEnt
     pthread_mutex_unlock(&h->formLock);
     if (!base)
         return SPGPU_OUTOFMEMORY;
-    *counts = (int*)base;
-    *entries = (SpgpuDeepEntry*)(base + countBytes);
-    *partials = base + countBytes + slots * sizeof(SpgpuDeepEntry);
+    list->header = (int*)base;
+    list->entries = (SpgpuDeepEntry*)(base + headBytes);
+    list->itemEntry = (int*)(base + headBytes + entryBytes);
+    list->partials = base + headBytes + entryBytes + itemEntryBytes;
+    list->itemSums = base + headBytes + entryBytes + itemEntryBytes + partialBytes;
     return SPGPU_SUCCESS;
 }
 

@@ -72,11 +72,14 @@ template <typename T> struct SlabArgs {
     int tailLanes; /* TAIL kernels: switch to whole-wave rows when <= this many lanes are busy */
     int* feedback; /* pinned host ints the sample wavefronts report the form they saw to, or NULL */
     long long tileSpanLimit; /* a sample group whose columns span at most this many counts as "local" (x-tile form) */
-    /* DEEP kernels: 32-row sub-groups deeper than deepCap hand their columns >= deepCap to deepSpmvKernel */
+    /* DEEP kernels: 32-row sub-groups deeper than deepCap hand their columns >= deepCap to the deep kernels */
     int deepCap;
-    int* deepCounts;             /* [SPGPU_DEEP_QUEUES] entries registered per queue (may exceed the queue's capacity) */
-    SpgpuDeepEntry* deepEntries; /* [SPGPU_DEEP_QUEUES][SPGPU_DEEP_QUEUE_ENTRIES] */
-    T* deepPartials;             /* [..][..][32] row sums over the columns < deepCap */
+    int deepChunk;               /* columns per item */
+    int* deepHeader;             /* entries registered, items handed out (may exceed the capacities), finish ticket */
+    SpgpuDeepEntry* deepEntries; /* [SPGPU_DEEP_ENTRIES] */
+    int* deepItemEntry;          /* [SPGPU_DEEP_ITEMS] */
+    T* deepPartials;             /* [SPGPU_DEEP_ENTRIES][32] row sums over the columns < deepCap */
+    T* deepItemSums;             /* [SPGPU_DEEP_ITEMS][32] */
     int xcdRun;                  /* raggedSpmvKernel: row blocks per XCD run (0: hardware order) */
 };
 
@@ -106,14 +109,24 @@ template <int POLICY, typename T> __device__ inline T loadX(const T* p)
     }
 }
 
-/* Which deep queue a 32-row sub-group registers in.  A multiplicative hash, not the sub-group number modulo the number
- * of queues: after an ordering by length the deep sub-groups sit at the heads of the windows, i.e. at multiples of
- * window / 32, and modulo 1024 all of them would meet in 16 queues (measured: queue overflow and a serial deep kernel). */
-__device__ inline int deepQueueOf(long long subGroup)
+/* One lane registers a 32-row sub-group deeper than deepCap in the handle's deep list: an entry, and one item per
+ * deepChunk columns beyond the cap.  Returns the entry, or -1 when the list is full -- the sub-group then stays with
+ * the main kernel.  (The list is global: which entry a sub-group gets depends on scheduling, its sum does not.) */
+template <typename T> __device__ inline int deepRegister(const SlabArgs<T>& a, int row0, int depth)
 {
-    return (int)(((unsigned)subGroup * 2654435761u) >> (32 - 10)) & (SPGPU_DEEP_QUEUES - 1);
+    const int items = (depth - a.deepCap + a.deepChunk - 1) / a.deepChunk;
+    const int entry = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES], 1);
+    if (entry >= SPGPU_DEEP_ENTRIES)
+        return -1;
+    const int first = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_ITEMS], items);
+    const bool fits = first + items <= SPGPU_DEEP_ITEMS;
+    a.deepEntries[entry] = SpgpuDeepEntry{row0, depth, first, fits ? items : 0};
+    if (!fits)
+        return -1;
+    for (int c = 0; c < items; ++c)
+        a.deepItemEntry[first + c] = entry;
+    return entry;
 }
-static_assert(SPGPU_DEEP_QUEUES == 1024, "deepQueueOf keeps 10 bits");
 
 /* Function-scope LDS: only kernels that call this allocate it (the forms without a tile keep 0 bytes of LDS). */
 template <typename E, int N> __device__ inline E* ldsArray()
@@ -303,9 +316,9 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
     }
     /* DEEP: one very long row (or a hack of them, after the rows were ordered by length) would keep this wavefront
      * streaming long after the rest of the grid has drained -- a single wavefront moves a few GB/s.  A 32-row
-     * sub-group deeper than deepCap therefore keeps only its first deepCap columns here; it registers itself in a
-     * deep queue and deepSpmvKernel, launched right behind this kernel, spreads the remaining columns -- in chunks,
-     * over the wavefronts of a workgroup -- adds the sums below and writes z.  A full queue: the sub-group stays here. */
+     * sub-group deeper than deepCap therefore keeps only its first deepCap columns here; it registers itself in the
+     * deep list and the deep kernels, launched right behind this kernel, spread the remaining columns -- in chunks,
+     * a wavefront each -- add the sums below and write z.  A full list: the sub-group stays here. */
     int deepSlot = -1;
     if constexpr (DEEP) {
         static_assert(PH == 1, "the deep split is built for the shapes in which a lane walks whole rows");
@@ -317,15 +330,8 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
             subDepth = other > subDepth ? other : subDepth;
         }
         int slot = -1;
-        if (lane % SUB == 0 && subDepth > a.deepCap) {
-            /* queue = the workgroup of deepSpmvKernel that will finish this sub-group */
-            const int queue = deepQueueOf(row0 >> 5);
-            const int at = atomicAdd(&a.deepCounts[queue], 1);
-            if (at < SPGPU_DEEP_QUEUE_ENTRIES) {
-                slot = queue * SPGPU_DEEP_QUEUE_ENTRIES + at;
-                a.deepEntries[slot] = SpgpuDeepEntry{(int)row0, subDepth};
-            }
-        }
+        if (lane % SUB == 0 && subDepth > a.deepCap)
+            slot = deepRegister(a, (int)row0, subDepth);
         deepSlot = __shfl(slot, lane & ~(SUB - 1), kWave);
         if (deepSlot >= 0) {
             laneLongest = 0;
@@ -634,7 +640,7 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
         return;
 
     if constexpr (DEEP) {
-        if (deepSlot >= 0) { /* raw sums: deepSpmvKernel finishes these rows */
+        if (deepSlot >= 0) { /* raw sums: deepFinishKernel finishes these rows */
 #pragma unroll
             for (int t = 0; t < RPL; ++t)
                 a.deepPartials[(size_t)deepSlot * 32 + (size_t)((row0 + t) & 31)] = sum[t];
@@ -675,166 +681,170 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
 }
 
 /*
- * The columns >= deepCap of the sub-groups (32 rows) the DEEP form of slabSpmvKernel registered.  Workgroup q owns
- * queue q.  The remaining columns of a sub-group are cut into chunks of CHUNK columns; the (sub-group, chunk) items of
- * the whole queue are dealt to the workgroup's wavefronts, WAVES per pass -- so a queue of many shallow sub-groups keeps
- * every wavefront busy just as one very deep sub-group does.  A wavefront reads a chunk the way the format stores it:
- * 32/RPL lanes with RPL rows each cover a slab column, PH = 64 / (32/RPL) columns per load instruction, UNROLL of them
- * per stage.  Sum of one row: what slabSpmvKernel left in deepPartials, plus the chunk sums in chunk order; a chunk sum
- * = its PH phase sums (each over ascending k) combined pairwise.  The oracle restates exactly this (orc_?spmv_deep).
+ * The columns >= deepCap of the sub-groups (32 rows) a DEEP main kernel registered, in two launches right behind it.
+ *
+ * deepItemsKernel: a wavefront per item, an item = CHUNK columns of one sub-group.  The wavefront reads the chunk the
+ * way the format stores it -- 32/RPL lanes with RPL rows each cover a slab column, PH = 64 / (32/RPL) columns per load
+ * instruction -- UNROLL load instructions per stage, the next stage requested behind the current stage's gathers.  The
+ * items of one very deep sub-group and of many shallow ones alike spread over the whole chip (measured before, with a
+ * workgroup per hashed queue of sub-groups: 87-139 us for 108 MB, the grid waiting for its fullest queue).
+ * A chunk sum = its PH phase sums (each over ascending k) combined pairwise; it goes to deepItemSums.
  * x comes from global memory: these are the few long rows, their own columns give them their locality.
- * Only workgroup q reads or resets queue q, so nothing here depends on another workgroup.
+ *
+ * deepFinishKernel: 32 lanes per entry.  Sum of one row = what the main kernel left in deepPartials, plus the chunk
+ * sums in chunk order (orc_?spmv_deep restates exactly this); then the SpMV epilogue and the store through rIdx.  The
+ * workgroup that finishes last zeroes the header: every workgroup has read it by then, and the next call finds an
+ * empty list (a captured graph can be replayed).
  */
-template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int CHUNK>
-__global__ __launch_bounds__(WAVES * kWave) void deepSpmvKernel(const SlabArgs<T> a)
+template <typename T, int RPL, bool IS_HELL, int UNROLL, int CHUNK>
+__global__ __launch_bounds__(kBlockThreads) void deepItemsKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = 32 / RPL;    /* lanes per slab column of 32 rows */
     constexpr int PH = kWave / LPC;  /* columns per wave-wide load */
     constexpr int STEP = PH * UNROLL;
     static_assert(CHUNK % STEP == 0, "a chunk is a whole number of stages");
-    constexpr int QE = SPGPU_DEEP_QUEUE_ENTRIES;
-    __shared__ T chunkSum[WAVES][32];
-    __shared__ T total[QE][32];
-    __shared__ int firstItem[QE + 1];
-    __shared__ SpgpuDeepEntry entry[QE];
+    constexpr int WAVES = kBlockThreads / kWave;
 
-    const int queue = blockIdx.x;
-    const int registered = a.deepCounts[queue];
-    if (registered == 0)
-        return; /* the whole workgroup */
-    const int entries = registered < QE ? registered : QE;
+    const int registered = a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES];
+    const int handedOut = a.deepHeader[SPGPU_DEEP_HEAD_ITEMS];
+    const int entries = registered < SPGPU_DEEP_ENTRIES ? registered : SPGPU_DEEP_ENTRIES;
+    const int items = handedOut < SPGPU_DEEP_ITEMS ? handedOut : SPGPU_DEEP_ITEMS;
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
     const int sub = lane % LPC, phase = lane / LPC;
 
-    if (threadIdx.x < entries)
-        entry[threadIdx.x] = a.deepEntries[queue * QE + threadIdx.x];
-    for (int i = threadIdx.x; i < entries * 32; i += WAVES * kWave)
-        total[i >> 5][i & 31] = a.deepPartials[(size_t)queue * QE * 32 + i];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int items = 0;
-        for (int e = 0; e < entries; ++e) {
-            firstItem[e] = items;
-            items += (entry[e].depth - a.deepCap + CHUNK - 1) / CHUNK;
+    for (int item = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6); item < items; item += (int)gridDim.x * WAVES) {
+        /* items past a registration that did not fit carry whatever an earlier call left: check, do not trust */
+        const int e = a.deepItemEntry[item];
+        if (e < 0 || e >= entries)
+            continue;
+        const SpgpuDeepEntry entry = a.deepEntries[e];
+        const int chunk = item - entry.firstItem;
+        if (chunk < 0 || chunk >= entry.items)
+            continue;
+        const int kFirst = a.deepCap + chunk * CHUNK;
+        const int kEnd = kFirst + CHUNK < entry.depth ? kFirst + CHUNK : entry.depth;
+        const long long row0 = (long long)entry.row0 + (long long)sub * RPL;
+        long long slab = 0;
+        int len[RPL];
+        int laneLongest = 0;
+#pragma unroll
+        for (int t = 0; t < RPL; ++t) {
+            const long long r = row0 + t;
+            len[t] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+            len[t] = len[t] < kEnd ? len[t] : kEnd;
+            laneLongest = len[t] > laneLongest ? len[t] : laneLongest;
         }
-        firstItem[entries] = items;
-        a.deepCounts[queue] = 0; /* for the next call; this workgroup has its copy */
-    }
-    __syncthreads();
-    const int items = firstItem[entries];
-
-    for (int pass = 0; pass < items; pass += WAVES) {
-        const int item = pass + wave; /* wave-uniform */
-        if (item < items) {
-            int e = 0;
-            while (firstItem[e + 1] <= item)
-                ++e;
-            const int kFirst = a.deepCap + (item - firstItem[e]) * CHUNK;
-            const int kEnd = kFirst + CHUNK < entry[e].depth ? kFirst + CHUNK : entry[e].depth;
-            const long long row0 = (long long)entry[e].row0 + (long long)sub * RPL;
-            long long slab = 0;
-            int len[RPL];
-            int laneLongest = 0;
-#pragma unroll
-            for (int t = 0; t < RPL; ++t) {
-                const long long r = row0 + t;
-                len[t] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
-                len[t] = len[t] < kEnd ? len[t] : kEnd;
-                laneLongest = len[t] > laneLongest ? len[t] : laneLongest;
+        if (row0 < a.rows) {
+            if constexpr (IS_HELL) {
+                const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
+                const unsigned hack = r0 / hs;
+                slab = (long long)a.hackOffsets[hack] + (r0 - hack * hs);
+            } else {
+                slab = row0;
             }
-            if (row0 < a.rows) {
-                if constexpr (IS_HELL) {
-                    const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
-                    const unsigned hack = r0 / hs;
-                    slab = (long long)a.hackOffsets[hack] + (r0 - hack * hs);
+        }
+        const T* __restrict__ vals = a.cM + slab;
+        const int* __restrict__ idxs = a.rP + slab;
+        T sum[RPL];
+#pragma unroll
+        for (int t = 0; t < RPL; ++t)
+            sum[t] = zeroOf<T>();
+
+        struct Stage {
+            Pack<T, RPL> v[UNROLL];
+            Pack<int, RPL> c[UNROLL];
+        };
+        auto fetch = [&](int kBase, Stage& s) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = kBase + u * PH + phase;
+                if (k < laneLongest) {
+                    s.v[u] = loadPack<true, T, RPL>(vals + (long long)k * a.valStride);
+                    s.c[u] = loadPack<true, int, RPL>(idxs + (long long)k * a.idxStride);
                 } else {
-                    slab = row0;
-                }
-            }
-            const T* __restrict__ vals = a.cM + slab;
-            const int* __restrict__ idxs = a.rP + slab;
-            T sum[RPL];
-#pragma unroll
-            for (int t = 0; t < RPL; ++t)
-                sum[t] = zeroOf<T>();
-
-            struct Stage {
-                Pack<T, RPL> v[UNROLL];
-                Pack<int, RPL> c[UNROLL];
-            };
-            auto fetch = [&](int kBase, Stage& s) {
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int k = kBase + u * PH + phase;
-                    if (k < laneLongest) {
-                        s.v[u] = loadPack<true, T, RPL>(vals + (long long)k * a.valStride);
-                        s.c[u] = loadPack<true, int, RPL>(idxs + (long long)k * a.idxStride);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < RPL; ++t) {
-                            s.v[u].v[t] = zeroOf<T>();
-                            s.c[u].v[t] = a.baseIndex;
-                        }
-                    }
-                }
-            };
-            Stage cur, nxt;
-            fetch(kFirst, cur);
-            for (int kBase = kFirst; kBase < kEnd; kBase += STEP) {
-                T xv[UNROLL][RPL];
-                bool use[UNROLL][RPL];
-#pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int k = kBase + u * PH + phase;
 #pragma unroll
                     for (int t = 0; t < RPL; ++t) {
-                        const int col = cur.c[u].v[t] - a.baseIndex;
-                        use[u][t] = k < len[t] && col >= 0;
-                        xv[u][t] = a.x[use[u][t] ? col : 0];
+                        s.v[u].v[t] = zeroOf<T>();
+                        s.c[u].v[t] = a.baseIndex;
                     }
                 }
-                fetch(kBase + STEP, nxt); /* behind the gathers in vmcnt order: stays in flight while they are used */
+            }
+        };
+        Stage cur, nxt;
+        fetch(kFirst, cur);
+        for (int kBase = kFirst; kBase < kEnd; kBase += STEP) {
+            T xv[UNROLL][RPL];
+            bool use[UNROLL][RPL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = kBase + u * PH + phase;
 #pragma unroll
-                    for (int t = 0; t < RPL; ++t)
-                        sum[t] = pick(use[u][t], mulAdd(cur.v[u].v[t], xv[u][t], sum[t]), sum[t]);
+                for (int t = 0; t < RPL; ++t) {
+                    const int col = cur.c[u].v[t] - a.baseIndex;
+                    use[u][t] = k < len[t] && col >= 0;
+                    xv[u][t] = a.x[use[u][t] ? col : 0];
                 }
-                cur = nxt;
             }
+            fetch(kBase + STEP, nxt); /* behind the gathers in vmcnt order: stays in flight while they are used */
 #pragma unroll
-            for (int m = LPC; m < kWave; m <<= 1) {
-#pragma unroll
-                for (int t = 0; t < RPL; ++t)
-                    sum[t] = add(sum[t], laneXor(sum[t], m));
-            }
-            if (phase == 0) {
+            for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
                 for (int t = 0; t < RPL; ++t)
-                    chunkSum[wave][sub * RPL + t] = sum[t];
+                    sum[t] = pick(use[u][t], mulAdd(cur.v[u].v[t], xv[u][t], sum[t]), sum[t]);
             }
+            cur = nxt;
         }
-        __syncthreads();
-        /* items are numbered sub-group by sub-group, chunks ascending: adding in item order is adding in chunk order */
-        if (threadIdx.x < 32) {
-            int e = 0;
-            for (int w = 0; w < WAVES && pass + w < items; ++w) {
-                while (firstItem[e + 1] <= pass + w)
-                    ++e;
-                total[e][threadIdx.x] = add(total[e][threadIdx.x], chunkSum[w][threadIdx.x]);
-            }
+#pragma unroll
+        for (int m = LPC; m < kWave; m <<= 1) {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                sum[t] = add(sum[t], laneXor(sum[t], m));
         }
-        __syncthreads();
+        if (phase == 0) {
+#pragma unroll
+            for (int t = 0; t < RPL; ++t)
+                a.deepItemSums[(size_t)item * 32 + (size_t)(sub * RPL + t)] = sum[t];
+        }
     }
+}
 
+template <typename T>
+__global__ __launch_bounds__(kBlockThreads) void deepFinishKernel(const SlabArgs<T> a)
+{
+    const int registered = a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES];
+    const int entries = registered < SPGPU_DEEP_ENTRIES ? registered : SPGPU_DEEP_ENTRIES;
     const bool hasBeta = isNotZero(a.beta);
-    for (int i = threadIdx.x; i < entries * 32; i += WAVES * kWave) {
-        const long long r = (long long)entry[i >> 5].row0 + (i & 31);
-        if (r < a.rows) {
-            const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
-            a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, total[i >> 5][i & 31], a.beta, a.y[outRow])
-                                  : epilogue<false>(a.alpha, total[i >> 5][i & 31], a.beta, zeroOf<T>());
+    const int rowInGroup = threadIdx.x & 31;
+    constexpr int PER_BLOCK = kBlockThreads / 32;
+    for (int e = (int)blockIdx.x * PER_BLOCK + (int)(threadIdx.x >> 5); e < entries; e += (int)gridDim.x * PER_BLOCK) {
+        const SpgpuDeepEntry entry = a.deepEntries[e];
+        const long long r = (long long)entry.row0 + rowInGroup;
+        if (entry.items <= 0 || r >= a.rows)
+            continue;
+        T total = a.deepPartials[(size_t)e * 32 + rowInGroup];
+        constexpr int BATCH = 8; /* item sums requested together; added in item order */
+        for (int c0 = 0; c0 < entry.items; c0 += BATCH) {
+            T part[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (c0 + u < entry.items)
+                    part[u] = a.deepItemSums[(size_t)(entry.firstItem + c0 + u) * 32 + rowInGroup];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+                if (c0 + u < entry.items)
+                    total = add(total, part[u]);
+        }
+        const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+        a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, total, a.beta, a.y[outRow])
+                              : epilogue<false>(a.alpha, total, a.beta, zeroOf<T>());
+    }
+    __syncthreads(); /* every wavefront of this workgroup has used the header */
+    if (threadIdx.x == 0) {
+        const int ticket = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_TICKET], 1);
+        if (ticket == (int)gridDim.x - 1) {
+            a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES] = 0;
+            a.deepHeader[SPGPU_DEEP_HEAD_ITEMS] = 0;
+            a.deepHeader[SPGPU_DEEP_HEAD_TICKET] = 0;
         }
     }
 }
@@ -919,12 +929,16 @@ static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
     }
 }
 
-/* Right behind a DEEP kernel: a workgroup per queue; the workgroups whose queue is empty leave at once. */
+/* Right behind a DEEP kernel.  Fixed grids (the number of items is known on the device only): with nothing
+ * registered both kernels read the header and leave. */
+constexpr int kDeepChunk = 64;
 template <typename T, int RPL, bool IS_HELL>
 static void launchDeep(hipStream_t stream, const SlabArgs<T>& a)
 {
-    constexpr int UNROLL = 2; /* <= 64 VGPRs: all the queues' workgroups are resident at once */
-    hipLaunchKernelGGL((deepSpmvKernel<T, RPL, IS_HELL, UNROLL, 8, 128>), dim3(SPGPU_DEEP_QUEUES), dim3(8 * kWave), 0, stream, a);
+    constexpr int PH = kWave / (32 / RPL);
+    constexpr int UNROLL = 32 / PH; /* 32 columns per stage, two stages per item */
+    hipLaunchKernelGGL((deepItemsKernel<T, RPL, IS_HELL, UNROLL, kDeepChunk>), dim3(2048), dim3(kBlockThreads), 0, stream, a);
+    hipLaunchKernelGGL((deepFinishKernel<T>), dim3(256), dim3(kBlockThreads), 0, stream, a);
 }
 
 template <typename T, bool IS_HELL>
@@ -984,15 +998,23 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
                      (variant == 21 || variant == 22);
     a.deepCap = tune->deepCap > 0 ? tune->deepCap : 256;
     a.xcdRun = tune->xcdOrder;
-    a.deepCounts = nullptr;
+    a.deepChunk = kDeepChunk;
+    a.deepHeader = nullptr;
     a.deepEntries = nullptr;
+    a.deepItemEntry = nullptr;
     a.deepPartials = nullptr;
+    a.deepItemSums = nullptr;
     if (deepSplit) {
-        void* partials = nullptr;
-        if (spgpuDeepScratch(handle, &a.deepCounts, &a.deepEntries, &partials) == SPGPU_SUCCESS)
-            a.deepPartials = static_cast<T*>(partials);
-        else
+        SpgpuDeepList list;
+        if (spgpuDeepScratch(handle, &list) == SPGPU_SUCCESS) {
+            a.deepHeader = list.header;
+            a.deepEntries = list.entries;
+            a.deepItemEntry = list.itemEntry;
+            a.deepPartials = static_cast<T*>(list.partials);
+            a.deepItemSums = static_cast<T*>(list.itemSums);
+        } else {
             deepSplit = false;
+        }
     }
     if (deepSplit && tune->ragged != 0) {
         /* the queue-driven kernel for rows ordered by length (ragged_spmv.hip.h); x through an LDS tile unless the

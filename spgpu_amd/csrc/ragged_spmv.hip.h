@@ -18,8 +18,8 @@
  *     stage of the current one, and the stream never stops for a dependent look-up.
  *   - the slice of x the workgroup's rows touch is staged in LDS (as in the x-tile form of slabSpmvKernel); entries
  *     outside it are gathered from global memory.
- *   - sub-groups deeper than deepCap keep their first deepCap columns here and hand the rest to deepSpmvKernel
- *     through the deep queues (see slabSpmvKernel, DEEP).
+ *   - sub-groups deeper than deepCap keep their first deepCap columns here and hand the rest to the deep kernels
+ *     through the handle's deep list (see slabSpmvKernel, DEEP).
  *
  * Algorithmic bytes as for slabSpmvKernel, plus 4 per row for rIdx.
  */
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
     __shared__ int lens[ROWS];        /* row lengths as walked here (deep sub-groups: cut at deepCap) */
     __shared__ int bases[ROWS / RPL]; /* first slot of every RPL-row strip, in elements */
     __shared__ int depths[SUBS];      /* longest walked row of every sub-group */
-    __shared__ int deepSlots[SUBS];   /* its entry in the deep queues, or -1 */
+    __shared__ int deepSlots[SUBS];   /* its entry in the deep list, or -1 */
     __shared__ int nextItem;
     __shared__ ColumnProbe seen[WAVES];
 
@@ -100,15 +100,8 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
         }
         int slot = -1;
         if constexpr (DEEP) {
-            if ((lane & 31) == 0 && depth > a.deepCap && i < ROWS) {
-                const long long sub0 = (blockRow0 + i) >> 5;
-                const int queue = deepQueueOf(sub0);
-                const int at = atomicAdd(&a.deepCounts[queue], 1);
-                if (at < SPGPU_DEEP_QUEUE_ENTRIES) {
-                    slot = queue * SPGPU_DEEP_QUEUE_ENTRIES + at;
-                    a.deepEntries[slot] = SpgpuDeepEntry{(int)(sub0 << 5), depth};
-                }
-            }
+            if ((lane & 31) == 0 && depth > a.deepCap && i < ROWS)
+                slot = deepRegister(a, (int)(blockRow0 + i), depth);
             slot = __shfl(slot, lane & 32, kWave);
         }
         if (i < ROWS) {

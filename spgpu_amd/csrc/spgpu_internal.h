@@ -32,7 +32,7 @@ typedef struct SpgpuPrivateHandle {
     unsigned formNext;
     pthread_mutex_t formLock; /* guards formKey / formRows / formNext */
     int spmvForm;             /* SPGPU_SPMV_FORM_* set by spgpuSetSpmvForm (atomic) */
-    void* deepScratch;        /* device: queue counts | entries | partials; NULL until first needed */
+    void* deepScratch;        /* device: the deep list (SpgpuDeepList); NULL until first needed */
     int lastSpmvForm;         /* form of the most recent ELL/HELL SpMV launch (diagnostic, atomic) */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8
@@ -43,18 +43,29 @@ static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
     return (SpgpuPrivateHandle*)(void*)h;
 }
 
-/* Deep queues of the ELL/HELL SpMV (csrc/ellpack_spmv.hip, DEEP form): device memory owned by the handle, allocated on
- * the first call that needs it.  SPGPU_DEEP_QUEUES queues of SPGPU_DEEP_QUEUE_ENTRIES entries; queue q belongs to
- * workgroup q of deepSpmvKernel, which empties it.  One SpMV of a handle uses the queues at a time (calls on one stream
- * do, in order). */
+/* Deep list of the ELL/HELL SpMV (csrc/ellpack_spmv.hip, DEEP form): device memory owned by the handle, allocated on
+ * the first call that needs it.  The main kernel registers every 32-row sub-group deeper than deepCap as one ENTRY and
+ * its columns beyond the cap as ITEMS of deepChunk columns; deepItemsKernel gives every item to a wavefront,
+ * deepFinishKernel adds an entry's item sums in item order, writes z and -- the workgroup that finishes last -- zeroes the
+ * header for the next call.  One SpMV of a handle uses the list at a time (calls on one stream do, in order). */
 typedef struct SpgpuDeepEntry {
-    int row0;  /* first row of the 32-row sub-group (a multiple of 32) */
-    int depth; /* its longest row */
+    int row0;      /* first row of the 32-row sub-group (a multiple of 32) */
+    int depth;     /* its longest row */
+    int firstItem; /* its items are firstItem .. firstItem + items - 1 */
+    int items;     /* 0: the item list was full, the main kernel kept the whole sub-group */
 } SpgpuDeepEntry;
-#define SPGPU_DEEP_QUEUES 1024
-#define SPGPU_DEEP_QUEUE_ENTRIES 32
-/* Device pointers of the queues (counts, entries, 32 * 16 bytes of row sums per entry), or SPGPU_OUTOFMEMORY. */
-spgpuStatus_t spgpuDeepScratch(spgpuHandle_t h, int** counts, SpgpuDeepEntry** entries, void** partials);
+#define SPGPU_DEEP_ENTRIES 8192
+#define SPGPU_DEEP_ITEMS 20480
+enum { SPGPU_DEEP_HEAD_ENTRIES = 0, SPGPU_DEEP_HEAD_ITEMS = 1, SPGPU_DEEP_HEAD_TICKET = 2, SPGPU_DEEP_HEAD_INTS = 64 };
+typedef struct SpgpuDeepList {
+    int* header;             /* [SPGPU_DEEP_HEAD_INTS]: entries registered, items handed out (both may exceed the capacity), finish ticket */
+    SpgpuDeepEntry* entries; /* [SPGPU_DEEP_ENTRIES] */
+    int* itemEntry;          /* [SPGPU_DEEP_ITEMS] entry of every item */
+    void* partials;          /* [SPGPU_DEEP_ENTRIES][32] x 16 bytes: row sums over the columns < deepCap */
+    void* itemSums;          /* [SPGPU_DEEP_ITEMS][32] x 16 bytes */
+} SpgpuDeepList;
+/* Device pointers of the list, or SPGPU_OUTOFMEMORY. */
+spgpuStatus_t spgpuDeepScratch(spgpuHandle_t h, SpgpuDeepList* list);
 
 /* With -DSPGPU_DEBUG every launch is followed by a synchronising error check
  * that prints and exits, as the reference does under -DDEBUG

@@ -340,6 +340,8 @@ def ragged_coo_on_device(lengths, n_cols, pattern="near", near=2048, letter="D",
     pattern "near":   the range is [row - near, row + near), wrapped into [0, n_cols) -- the locality of a mesh or a
                       banded problem, without consecutive columns
     pattern "random": the range is all of [0, n_cols)
+    pattern "band":   consecutive columns centred on the row, [row - L/2, row + L - L/2) wrapped -- BASELINE
+                      configs[1]'s band (i-16 .. i+15) with the row's own length
 
     Returns (rows int32, cols int32, vals) torch tensors; nnz = sum(lengths)."""
     import torch
@@ -357,6 +359,8 @@ def ragged_coo_on_device(lengths, n_cols, pattern="near", near=2048, letter="D",
         width = 2 * near
         assert int(L.max().item()) <= width
         cols = (row - near + ((k.to(torch.float64) + u) * width / length.to(torch.float64)).to(torch.int64)) % n_cols
+    elif pattern == "band":
+        cols = (row - length // 2 + k) % n_cols
     elif pattern == "random":
         cols = torch.clamp(((k.to(torch.float64) + u) * n_cols / length.to(torch.float64)).to(torch.int64), max=n_cols - 1)
     else:

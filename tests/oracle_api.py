@@ -423,9 +423,9 @@ for _L, _T in SCALAR.items():
                    i32, i32, i32]
 
 DEEP_CAP = 256   # SPGPU_DEEP_CAP default
-# deepSpmvKernel (csrc/ellpack_spmv.hip launchDeep): phases = 64 / (32 / rows per lane); chunks of 128 columns
-DEEP_SHAPE = {"S": dict(deep_phases=8, deep_chunk=128), "D": dict(deep_phases=4, deep_chunk=128),
-              "C": dict(deep_phases=4, deep_chunk=128), "Z": dict(deep_phases=2, deep_chunk=128)}
+# deepItemsKernel (csrc/ellpack_spmv.hip launchDeep): phases = 64 / (32 / rows per lane); items of 64 columns
+DEEP_SHAPE = {"S": dict(deep_phases=8, deep_chunk=64), "D": dict(deep_phases=4, deep_chunk=64),
+              "C": dict(deep_phases=4, deep_chunk=64), "Z": dict(deep_phases=2, deep_chunk=64)}
 
 
 def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_rows=128, rows_per_lane=2, step=8,
@@ -473,7 +473,7 @@ def default_spmv(mat, x, y, alpha, beta, r_idx=None):
     L = mat["letter"]
     if r_idx is not None:
         # a row order selects the queue-driven kernel (ragged_spmv.hip.h) with the deep split: sub-groups deeper than
-        # 128 columns are finished by deepSpmvKernel
+        # the cap are finished by the deep kernels
         return spmv_tail(mat, x, y, alpha, beta, r_idx=r_idx, **slab_shape(L, "ragged", deep_cap=DEEP_CAP))
     if L in TAIL_SHAPE:
         return spmv_tail(mat, x, y, alpha, beta, r_idx=r_idx, **TAIL_SHAPE[L])

@@ -244,7 +244,7 @@ def test_deep_split_every_type_bit_exact(gpu, tuning, name, form, cap):
 
 
 def test_deep_queue_overflow_stays_correct(gpu, tuning):
-    """More deep sub-groups than the queue holds (cap 1 on 1.2 M rows of length 3: 37 500 sub-groups, capacity 32 768):
+    """More deep sub-groups than the deep list holds (cap 1 on 1.2 M rows of length 3: 37 500 sub-groups, capacity 8 192):
     the surplus is summed by the main kernel; which sub-groups those are depends on scheduling, so the check is the
     north_star bound, not bits -- and a second call must give the same rows the same treatment or not, still in bound."""
     import torch
@@ -270,7 +270,7 @@ def test_deep_queue_overflow_stays_correct(gpu, tuning):
 def test_ragged_kernel_through_ridx_bit_exact(gpu, tuning, letter, shape, form, window, long_rows, pattern, hack):
     """The queue-driven kernel a row order selects (ragged_spmv.hip.h) with the deep split behind it: all four types,
     hack sizes 32 / 64 / 96, every workgroup shape, tile and gathers, beta != 0 and in place; against the oracle in the
-    kernel's order (2 * rows-per-lane phases, chunks of 128 columns beyond the cap) bit for bit."""
+    kernel's order (2 * rows-per-lane phases, items of 64 columns beyond the cap) bit for bit."""
     import torch
     from spgpu_amd import capi, formats, synth
     tuning(SPGPU_RAGGED_SHAPE=shape)

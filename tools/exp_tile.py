@@ -123,7 +123,7 @@ if "powerlaw" in cases:
         rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 2048, letter, seed=5)
         torch.cuda.synchronize()
         orders = [("plain", None), ("sorted all", (0, 0))]
-        if pattern == "near":
+        if pattern in ("near", "band"):
             pairs = [tuple(int(v) for v in item.split(":")) for item in os.environ.get("EXP_ORDERS", "2048:128,2048:256,4096:256,8192:256,16384:0").split(",")]
             orders += [(f"sorted window {w} long>{t}", (w, t)) for w, t in pairs]
         if os.environ.get("EXP_ONLY_WINDOWED"):
