@@ -241,6 +241,10 @@ def bench_powerlaw(args, handle, stream, dev, rows):
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     out = dict(rows=rows, mean_len=round(float(lengths.mean()), 2), max_len=int(lengths.max()),
                order="spgpuOellOrderDevice(window=2048, longRows=256) + spgpuCooPermuteRowsDevice + spgpuCooToHellDevice")
+    # the first ordering of a process pays rocPRIM's and the allocator's cold start (1.2 s measured): not the build time
+    warm = synth.ragged_coo_on_device(lengths[:4096], 4096, "near", 2048, letter, seed=5, device=dev)
+    formats.coo_to_ordered_hell_device(handle, 4096, *warm, letter, 32, 2048, 256, order=True)
+    del warm
     for pattern in ("near", "band", "random"):
         coo = synth.ragged_coo_on_device(lengths, rows, pattern, 2048, letter, seed=5, device=dev)
         torch.cuda.synchronize()
