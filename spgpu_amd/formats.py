@@ -146,7 +146,7 @@ def oell_order(row_lengths, window=0, long_rows=0):
 
 
 def coo_to_ordered_hell_device(handle, n_rows, coo_rows, coo_cols, coo_vals, letter, hack_size=32, window=0, long_rows=0,
-                               coo_base=0, hell_base=0, order=True):
+                               coo_base=0, hell_base=0, order=True, r_idx_given=None):
     """COO arrays in HBM (torch tensors) -> HELL in HBM with its rows ordered by length, all through the C ABI:
     spgpuCooRowLengthsDevice -> spgpuOellOrderDevice -> spgpuCooPermuteRowsDevice -> spgpuCooRowLengthsDevice ->
     spgpuHellPlanDevice -> spgpuCooToHellDevice.  order=False skips the ordering (plain HELL, rIdx None).
@@ -166,8 +166,11 @@ def coo_to_ordered_hell_device(handle, n_rows, coo_rows, coo_cols, coo_vals, let
         order_work = torch.empty(capi.spgpuOellOrderWorkBytes(n_rows), dtype=torch.uint8, device=dev)
         r_idx = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
         sorted_lengths = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
-        ok(capi.spgpuOellOrderDevice(handle, _dp(r_idx), _dp(sorted_lengths), _dp(lengths), n_rows, window, long_rows,
-                                     _dp(order_work)))
+        if r_idx_given is not None:      # experiments: an order computed elsewhere (any permutation of the rows)
+            r_idx.copy_(r_idx_given)
+        else:
+            ok(capi.spgpuOellOrderDevice(handle, _dp(r_idx), _dp(sorted_lengths), _dp(lengths), n_rows, window, long_rows,
+                                         _dp(order_work)))
         inverse = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
         rows_in = torch.empty_like(coo_rows)
         ok(capi.spgpuCooPermuteRowsDevice(handle, _dp(rows_in), _dp(coo_rows), nnz, _dp(r_idx), n_rows, coo_base, _dp(inverse)))

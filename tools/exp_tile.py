@@ -117,6 +117,23 @@ if "mild" in cases:
     del rows_t, cols_t, vals_t
     torch.cuda.empty_cache()
 
+def aligned_order(lengths, window, long_rows):
+    """Experiment: the long rows first (windows of 32 * window original rows), the others in windows of `window` rows
+    COUNTED AMONG THE SHORT ROWS and placed so that window boundaries are multiples of `window` in the new order."""
+    L = np.asarray(lengths, dtype=np.int64)
+    rows = np.arange(L.size, dtype=np.int64)
+    is_long = L > long_rows if long_rows > 0 else np.zeros(L.size, bool)
+    P = int(is_long.sum())
+    group = np.empty(L.size, np.int64)
+    group[is_long] = rows[is_long] // (32 * window)
+    long_groups = int(group[is_long].max()) + 1 if P else 0
+    rank = np.cumsum(~is_long) - 1
+    in_class = (P + rank[~is_long]) // window - P // window
+    group[~is_long] = long_groups + in_class
+    sign = np.where((np.where(is_long, group, group - long_groups) % 2) == 0, -1, 1)
+    return np.lexsort((rows * sign, L * sign, group)).astype(np.int32)
+
+
 if "powerlaw" in cases:
     lengths = synth.power_law_lengths(n, mean=32.0, max_len=2048, seed=5)
     for pattern in os.environ.get("EXP_PATTERNS", "near,random").split(","):
@@ -129,8 +146,12 @@ if "powerlaw" in cases:
         if os.environ.get("EXP_ONLY_WINDOWED"):
             orders = orders[2:]
         for name, order in orders:
+            given = None
+            if os.environ.get("EXP_ALIGNED") and order and order[0] > 0:
+                given = torch.from_numpy(aligned_order(lengths, *order)).cuda()
+                name += " ALIGNED"
             h = formats.coo_to_ordered_hell_device(handle, n, rows_t, cols_t, vals_t, letter, 32, *(order or (0, 0)),
-                                                   order=order is not None)
+                                                   order=order is not None, r_idx_given=given)
             forms = ["gather"] if (pattern == "random" or order is None or order == (0, 0)) else os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(",")
             run(h, f"power-law {pattern}, {name}", forms)
             del h
