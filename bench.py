@@ -372,6 +372,31 @@ def bench_c3(handle, stream, dev, rows, ell_rows):
                            hbm_gbs=round(alg / t * 1e-9, 1), frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4),
                            footprint_GB=round((e["pitch"] * e["max_row"] * 8 + ne * 4) * 1e-9, 2))
     out["ell_footprint_GB_at_full_rows"] = round(((n + 31) // 32 * 32) * int(lengths.max()) * 8e-9 + n * 4e-9, 1)
+    del e, x, z
+    torch.cuda.empty_cache()
+    # the same lengths with the rows ordered by length on the device (the reference's third format, OELL/OHELL:
+    # hellPerf.cpp:324-378): what is left of HELL's footprint, and the time (random columns: still gather-bound)
+    from spgpu_amd import formats
+    coo = synth.ragged_coo_on_device(lengths, n, "random", 2048, "S", seed=5, device=dev)
+    h = formats.coo_to_ordered_hell_device(handle, n, *coo, "S", 32, 2048, 256)
+    del coo
+    x, z = synth.device_vector(n, "S", 3, dev), torch.zeros(n, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    capi.spgpuSetSpmvForm(handle, capi.FORM_GATHER)       # scattered columns: the caller says so (include/spgpu/tuning.h)
+    call = lambda: capi.hellspmv["S"](handle, p(z), None, 1.0, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
+                                      p(h["rIdx"]), 32, n, p(x), 0.0, 0)
+    time_launches(stream, call, 3)
+    t = time_launches(stream, call, 20) / 20
+    z.zero_()
+    torch.cuda.synchronize()
+    time_launches(stream, call, 1)
+    capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
+    alg = h["nnz"] * 8 + n * 8 + n * 4 + (n // 32) * 4 + n * 4
+    out["hell_fp32_rows_ordered"] = dict(rows=n, nnz=h["nnz"], ms=round(t * 1e3, 4), gflops=round(2.0 * h["nnz"] / t * 1e-9, 1),
+                                         hbm_gbs=round(alg / t * 1e-9, 1), frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4),
+                                         footprint_GB=round((h["slots"] * 8 + n * 8 + n // 32 * 4) * 1e-9, 2),
+                                         slots_per_nnz=round(h["slots"] / h["nnz"], 3),
+                                         parity=check_windows(h, x, z, "S", O.slab_shape("S", "ragged", deep_cap=O.DEEP_CAP)))
     return out
 
 
