@@ -1,3 +1,2 @@
 cd /root/repo
-start=$(date +%s)
-timeout -k 10 900 python bench.py > gpurun_out/bench_r02d.json 2> gpurun_out/bench_r02d.err; echo "bench rc $? in $(( $(date +%s) - start )) s"
+VARIANTS=0,10,11 timeout -k 10 300 python tools/ab_spmm.py banded 2>&1 | tail -4
