@@ -1,2 +1,2 @@
 cd /root/repo
-VARIANTS=0,10,11 timeout -k 10 300 python tools/ab_spmm.py banded 2>&1 | tail -4
+timeout -k 10 600 python -m pytest tests/test_gpu_oell_device.py -x -q -k "replayed_graph or two_handles" 2>&1 | tail -5
