@@ -1,2 +1,6 @@
 cd /root/repo
-timeout -k 10 600 python -m pytest tests/test_gpu_oell_device.py -x -q -k "replayed_graph or two_handles" 2>&1 | tail -5
+export EXP_PATTERNS=band,near EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256 EXP_FORMS=ragged0
+for cap in 256 512 768 1024 1280 1536 256 1024; do
+echo "cap $cap"
+SPGPU_DEEP_CAP=$cap timeout -k 10 300 python tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep "^D " | cut -c1-110
+done
