@@ -66,7 +66,9 @@ def run(h, label, forms):
     alg = h["nnz"] * (elem + 4) + rows * (4 + elem) + n * elem + hacks * 4 + (rows * 4 if h.get("rIdx") is not None else 0)
     call = lambda: capi.hellspmv[letter](handle, p(z), None, one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
                                          None if os.environ.get("EXP_DROP_RIDX") else p(h.get("rIdx")), 32, rows, p(x), zero, 0)
-    for form in forms:
+    for full in forms:
+        form, _, xcd = full.partition("x")          # "ragged0x4": shape 0 with runs of 4 row blocks per XCD
+        os.environ["SPGPU_XCD_ORDER"] = xcd or os.environ.get("EXP_XCD_ORDER", "0")
         os.environ["SPGPU_X_TILE_SHAPE"] = form[4:] if form.startswith("tile") else "0"
         os.environ["SPGPU_RAGGED"] = "1" if form.startswith("ragged") else "0"      # raggedN: shape N with the tile; raggedg: gathers
         os.environ["SPGPU_RAGGED_SHAPE"] = form[6:] if form.startswith("ragged") and form[6:].isdigit() else "0"
@@ -88,7 +90,7 @@ def run(h, label, forms):
         with torch.cuda.stream(stream):
             call()
         stream.synchronize()
-        print(f"{letter} {label:46s} {form:7s} slots/nnz {h['slots'] / h['nnz']:.3f}  {t:.4f} ms  {alg / t * 1e-6:7.1f} GB/s  "
+        print(f"{letter} {label:46s} {full:10s} slots/nnz {h['slots'] / h['nnz']:.3f}  {t:.4f} ms  {alg / t * 1e-6:7.1f} GB/s  "
               f"{alg / t * 1e-6 / 8000:.3f} of 8 TB/s  {check(h, form)}", flush=True)
     capi.spgpuSetSpmvForm(handle, 0)
 
