@@ -139,3 +139,55 @@ def test_random_case_within_the_bound(gpu, seed):
                                               worst, got[worst], want[worst])
         finally:
             capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_diagonal_case_within_the_bound(gpu, seed):
+    """HDIA built from COO, DIA, and HDIA built from DIA: a random set of diagonals (some only partly filled, some outside
+    short rectangular matrices), every type, hack sizes 1 ... 96, against extended precision."""
+    import torch
+    from spgpu_amd import capi, formats
+    rng = np.random.default_rng(1000 + seed)
+    letter = "SDCZ"[seed % 4]
+    n = int(rng.choice([1, 5, 32, 33, 257, 1000, 4099, 30011]))
+    cols_n = int(rng.choice([n, n + 40, max(1, n - 13)]))
+    hack = int(rng.choice([1, 2, 8, 30, 32, 33, 64, 96]))
+    count = int(rng.integers(1, 12))
+    offsets = np.unique(np.concatenate(([0], rng.integers(-min(n, 3000) + 1, min(cols_n, 3000), count))))
+    rows_l, cols_l = [], []
+    for off in offsets:
+        r = np.arange(n, dtype=np.int64)
+        c = r + off
+        keep = (c >= 0) & (c < cols_n) & (rng.random(n) < rng.choice([1.0, 1.0, 0.6, 0.05]))   # full, or with holes
+        rows_l.append(r[keep])
+        cols_l.append(c[keep])
+    rows, cols = np.concatenate(rows_l), np.concatenate(cols_l)
+    if rows.size == 0:
+        rows, cols = np.array([0], np.int64), np.array([0], np.int64)
+    nnz = int(rows.size)
+    real = O.NP_DTYPE[{"S": "S", "C": "S", "D": "D", "Z": "D"}[letter]]
+    vals = rng.standard_normal(nnz).astype(real)
+    if letter in "CZ":
+        vals = (vals + 1j * rng.standard_normal(nnz).astype(real)).astype(O.NP_DTYPE[letter])
+    perm = rng.permutation(nnz)
+    rows, cols, vals = rows[perm], cols[perm], vals[perm]
+    case = dict(letter=letter, n=n, rows=rows, cols=cols, vals=vals)
+    x, y = _vector(rng, letter, cols_n), _vector(rng, letter, n)
+    alpha = [1.0, -0.75, 2.5][int(rng.integers(0, 3))]
+    beta = [0.0, 1.0, -0.5][int(rng.integers(0, 3))]
+    want, scale = _exact(case, x, y, alpha, beta)
+    bound = TOL[letter] * scale + 1e-300
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    dia = formats.coo_to_dia(n, cols_n, rows, cols, vals)
+    mats = [("hdia from coo", formats.DeviceHdia(formats.coo_to_hdia(n, cols_n, rows, cols, vals, hack))),
+            ("dia", formats.DeviceDia(dia)),
+            ("hdia from dia", formats.DeviceHdia(formats.dia_to_hdia(dia, hack)))]
+    for name, mat in mats:
+        for in_place in ((False, True) if beta != 0 else (False,)):
+            dz = dy.clone() if in_place else torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            mat.spmv(gpu, dz, dz if in_place else (dy if beta != 0 else None), alpha, dx, beta)
+            torch.cuda.synchronize()
+            got = dz.cpu().numpy()
+            err = np.abs(got.astype(want.dtype) - want).astype(np.float64)
+            worst = int(np.argmax(err - bound))
+            assert np.all(err <= bound), (seed, letter, name, n, cols_n, hack, offsets.tolist(), worst, got[worst], want[worst])
