@@ -252,8 +252,9 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             t0 = time.perf_counter()
             h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, 2048, 256, order=ordered)
             build_s = time.perf_counter() - t0
-            # scattered columns: the LDS tile cannot help, the caller says so (include/spgpu/tuning.h)
-            capi.spgpuSetSpmvForm(handle, capi.FORM_GATHER if (ordered and pattern == "random") else capi.FORM_AUTO)
+            # form AUTO throughout: through rIdx the tile form falls back to gathers column by column, and on scattered
+            # columns it runs within 1 % of the plain gather form (tools/exp_tile.py, ragged0 vs raggedg)
+            capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
             call = lambda: capi.hellspmv[letter](handle, p(z), None, C.c_double(1.0), p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]),
                                                  p(h["rS"]), p(h["rIdx"]), 32, rows, p(x), C.c_double(0.0), 0)
             time_launches(stream, call, 3)
@@ -382,7 +383,7 @@ def bench_c3(handle, stream, dev, rows, ell_rows):
     del coo
     x, z = synth.device_vector(n, "S", 3, dev), torch.zeros(n, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
-    capi.spgpuSetSpmvForm(handle, capi.FORM_GATHER)       # scattered columns: the caller says so (include/spgpu/tuning.h)
+    capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
     call = lambda: capi.hellspmv["S"](handle, p(z), None, 1.0, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
                                       p(h["rIdx"]), 32, n, p(x), 0.0, 0)
     time_launches(stream, call, 3)

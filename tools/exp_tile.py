@@ -142,7 +142,7 @@ if "powerlaw" in cases:
         rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 2048, letter, seed=5)
         torch.cuda.synchronize()
         orders = [("plain", None), ("sorted all", (0, 0))]
-        if pattern in ("near", "band"):
+        if pattern in ("near", "band") or os.environ.get("EXP_WINDOWS_FOR_ALL"):
             pairs = [tuple(int(v) for v in item.split(":")) for item in os.environ.get("EXP_ORDERS", "2048:128,2048:256,4096:256,8192:256,16384:0").split(",")]
             orders += [(f"sorted window {w} long>{t}", (w, t)) for w, t in pairs]
         if os.environ.get("EXP_ONLY_WINDOWED"):
@@ -154,7 +154,7 @@ if "powerlaw" in cases:
                 name += " ALIGNED"
             h = formats.coo_to_ordered_hell_device(handle, n, rows_t, cols_t, vals_t, letter, 32, *(order or (0, 0)),
                                                    order=order is not None, r_idx_given=given)
-            forms = ["gather"] if (pattern == "random" or order is None or order == (0, 0)) else os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(",")
+            forms = ["gather"] if ((pattern == "random" and not os.environ.get("EXP_WINDOWS_FOR_ALL")) or order is None or order == (0, 0)) else os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(",")
             run(h, f"power-law {pattern}, {name}", forms)
             del h
             torch.cuda.empty_cache()
