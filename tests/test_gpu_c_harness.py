@@ -1,5 +1,5 @@
 """GPU: the plain-C callers of the C ABI (tools/*.c, built by `make tools`): the reference's ctest.c sequence,
-its hellPerf.cpp flow on a synthetic matrix, and a CG solve -- each checks itself and exits non-zero on failure."""
+its hellPerf.cpp flow (ELL, HELL, ordered ELL) on a synthetic matrix, and a CG solve -- each checks itself and exits non-zero on failure."""
 import os
 import subprocess
 
@@ -25,7 +25,7 @@ def test_ctest_sequence():
 @pytest.mark.parametrize("pattern,precision", [("banded", "d"), ("random", "s")])
 def test_hellperf_flow(pattern, precision):
     out = _run("hellperf_amd", 200000, 16, pattern, 20, precision)
-    assert "checksums identical: PASSED" in out
+    assert "checksums identical: PASSED" in out and "OELL checksum equal within rounding: PASSED" in out
 
 
 @pytest.mark.parametrize("precision", ["d", "s"])
@@ -47,6 +47,7 @@ def test_hellperf_on_a_matrix_market_file(tmp_path, precision):
     unfolded = 2 * len(lower) - n
     assert f"symmetric storage unfolded: {unfolded} entries" in out
     assert f"{n} rows, {n} columns, {unfolded} nnz" in out and "checksums identical: PASSED" in out
+    assert "OELL checksum equal within rounding: PASSED" in out
     rect = tmp_path / "rect.mtx"
     rows, cols, per_row = 1000, 1700, 4
     with open(rect, "w") as f:
@@ -61,6 +62,6 @@ def test_hellperf_on_a_matrix_market_file(tmp_path, precision):
 
 def test_cg_converges():
     out = _run("cg_amd", 128, 2000, 1e-10)
-    assert "PASSED" in out and "bit-identical to the eager run" in out
+    assert "PASSED" in out and out.count("bit-identical to the eager run") == 2     # the 8-kernel graph and the fused one
     last = [l for l in out.splitlines() if "relative residual" in l][-1]
     assert float(last.split("max |x - 1| =")[1]) < 1e-6

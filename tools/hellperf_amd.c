@@ -1,6 +1,6 @@
 /*
  * Plain-C performance harness with the flow of the reference's src/tests/hellPerf.cpp:127-317
- * (COO -> computeEllRowLenghts/cooToEll -> ELL run; computeHellAllocSize/ellToHell -> HELL run;
+ * (COO -> computeEllRowLenghts/cooToEll -> ELL run; computeHellAllocSize/ellToHell -> HELL run; ellToOell -> ordered ELL run;
  * per format: 1 warm-up, dot(z,z) printed as checksum, N timed launches, GFlop/s), on a Matrix Market
  * file as the reference's harness (symmetric storage unfolded, hellPerf.cpp:93-113) or on a synthetic
  * matrix (no .mtx ships with the reference), and with HIP in place of the CUDA runtime.  alpha = 1, beta = 0 as hellPerf.cpp:27-28.  Adds what the reference's harness
@@ -177,9 +177,45 @@ int main(int argc, char** argv)
         printf("%s dot res: %.10e | %.4f ms | %.1f GFlop/s | %.1f GB/s (%.1f%% of 8 TB/s)\n", format ? "HELL" : "ELL ",
                dots[format], t * 1e3, 2.0 * nnz / t * 1e-9, bytes / t * 1e-9, bytes / t * 1e-9 / 80.0);
     }
+    /* ---- third format of the reference's harness: ordered ELL (hellPerf.cpp:320-378).  ellToOell on the host, the
+     * row order handed to spgpu?ellspmv as rIdx.  (The reference's harness uploads the ordered row lengths to devRs but
+     * passes devEllRs -- the unordered ones -- to the kernel, hellPerf.cpp:342,352; here the ordered lengths are used.) ---- */
+    int* oellIdx = (int*)malloc(rows * sizeof(int));
+    int* oellLen = (int*)malloc(rows * sizeof(int));
+    void* oellV = calloc((size_t)maxRow * pitch, es);
+    int* oellI = (int*)calloc((size_t)maxRow * pitch, sizeof(int));
+    ellToOell(oellIdx, oellV, oellI, oellLen, ellV, ellI, rowLen, pitch, pitch, rows, type);
+    int* dRidx;
+    CHECK(hipMalloc((void**)&dRidx, rows * sizeof(int)));
+    CHECK(hipMemcpy(dRidx, oellIdx, rows * sizeof(int), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dRs, oellLen, rows * sizeof(int), hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dEllV, oellV, (size_t)maxRow * pitch * es, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dEllI, oellI, (size_t)maxRow * pitch * sizeof(int), hipMemcpyHostToDevice));
+#define RUN_OELL()                                                                                                  \
+    do {                                                                                                            \
+        if (dbl) spgpuDellspmv(h, dZ, dY, 1.0, dEllV, dEllI, pitch, pitch, dRs, dRidx, perRow, maxRow, rows, dX, 0.0, 0); \
+        else     spgpuSellspmv(h, dZ, dY, 1.0f, dEllV, dEllI, pitch, pitch, dRs, dRidx, perRow, maxRow, rows, dX, 0.0f, 0); \
+    } while (0)
+    RUN_OELL();
+    const double dotOell = dbl ? spgpuDdot(h, rows, dZ, dZ) : (double)spgpuSdot(h, rows, dZ, dZ);
+    {
+        hipStream_t s = spgpuGetStream(h);
+        CHECK(hipEventRecord(t0, s));
+        for (int i = 0; i < reps; ++i) RUN_OELL();
+        CHECK(hipEventRecord(t1, s));
+        CHECK(hipEventSynchronize(t1));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, t0, t1));
+        const double t = ms * 1e-3 / reps;
+        printf("OELL dot res: %.10e | %.4f ms | %.1f GFlop/s | %.1f GB/s (%.1f%% of 8 TB/s)\n", dotOell, t * 1e3, 2.0 * nnz / t * 1e-9,
+               (bytes + 4.0 * rows) / t * 1e-9, (bytes + 4.0 * rows) / t * 1e-9 / 80.0);
+    }
     spgpuDestroy(h);
     CHECK(hipGetLastError());
     const int same = dots[0] == dots[1];
-    printf(same ? "ELL and HELL checksums identical: PASSED\n" : "checksums differ: FAILED\n");
-    return same ? 0 : 1;
+    /* the ordered run adds a row's products in another order (the kernel for ordered rows): equal within rounding */
+    const int close = fabs(dotOell - dots[0]) <= (dbl ? 1e-10 : 1e-4) * fabs(dots[0]);
+    printf(same ? "ELL and HELL checksums identical: PASSED\n" : "ELL and HELL checksums differ: FAILED\n");
+    printf(close ? "OELL checksum equal within rounding: PASSED\n" : "OELL checksum differs: FAILED\n");
+    return same && close ? 0 : 1;
 }
