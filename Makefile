@@ -46,8 +46,8 @@ $(BUILD)/%.cpp.o: $(CSRC)/%.cpp $(HDRS)
 	@mkdir -p $(BUILD)
 	$(HIPCC) -x c++ $(CFLAGS) -std=c++17 -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include -c $< -o $@
 
-# Plain-C callers of the C ABI (gcc, no hipcc): the reference's ctest.c / hellPerf.cpp flows and a CG solver.
-TOOLS := tools/ctest_amd.bin tools/hellperf_amd.bin tools/cg_amd.bin
+# Plain-C callers of the C ABI (gcc, no hipcc): the reference's ctest.c / hellPerf.cpp / diaPerf.cpp flows and a CG solver.
+TOOLS := tools/ctest_amd.bin tools/hellperf_amd.bin tools/diaperf_amd.bin tools/cg_amd.bin
 tools: lib $(TOOLS)
 tools/%.bin: tools/%.c $(HDRS) $(LIBDIR)/libspgpu.so
 	gcc -O2 -std=gnu99 -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include -Iinclude $< -L$(LIBDIR) -lspgpu -L$(ROCM)/lib -lamdhip64 -lm \

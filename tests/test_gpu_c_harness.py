@@ -60,6 +60,29 @@ def test_hellperf_on_a_matrix_market_file(tmp_path, precision):
     assert f"{rows} rows, {cols} columns, {rows * per_row} nnz" in out and "checksums identical: PASSED" in out
 
 
+@pytest.mark.parametrize("m,points,precision", [(48, 7, "d"), (300, 5, "s")])
+def test_diaperf_flow(m, points, precision):
+    """The reference's diaPerf.cpp flow: COO -> DIA run, COO -> HDIA run, checksums dot(z,z) identical."""
+    out = _run("diaperf_amd", m, points, 10, precision)
+    assert "DIA and HDIA checksums identical: PASSED" in out
+
+
+def test_diaperf_on_a_matrix_market_file(tmp_path):
+    import numpy as np
+    n = 2000
+    rng = np.random.default_rng(9)
+    path = tmp_path / "band.mtx"
+    entries = [(i, i + off) for i in range(n) for off in (-40, -1, 0, 1, 7) if 0 <= i + off < n]
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{n} {n} {len(entries)}\n")
+        for i, j in entries:
+            f.write(f"{i + 1} {j + 1} {rng.standard_normal():.17g}\n")
+    out = _run("diaperf_amd", path, 5, "d")
+    assert f"{n} rows, {n} columns, {len(entries)} nnz" in out and "DIA 5 diagonals" in out
+    assert "DIA and HDIA checksums identical: PASSED" in out
+
+
 def test_cg_converges():
     out = _run("cg_amd", 128, 2000, 1e-10)
     assert "PASSED" in out and out.count("bit-identical to the eager run") == 2     # the 8-kernel graph and the fused one
