@@ -1016,6 +1016,9 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             deepSplit = false;
         }
     }
+    /* ELL says how long its longest row is: when none can exceed the cap nothing registers and the two launches behind
+     * the main kernel (~5 us each when empty) are left out; HELL does not say */
+    const bool deepPossible = IS_HELL || a.maxNnz > a.deepCap;
     if (deepSplit && tune->ragged != 0) {
         /* the queue-driven kernel for rows ordered by length (ragged_spmv.hip.h); x through an LDS tile unless the
          * caller asked for plain gathers */
@@ -1023,7 +1026,8 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         a.feedback = nullptr;
         spgpuNoteSpmvForm(handle, form != SPGPU_SPMV_FORM_GATHER ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
         launchRagged<T, WIDE, IS_HELL, true>(stream, a, tune->raggedShape, form != SPGPU_SPMV_FORM_GATHER);
-        launchDeep<T, WIDE, IS_HELL>(stream, a);
+        if (deepPossible)
+            launchDeep<T, WIDE, IS_HELL>(stream, a);
         return;
     }
     if (deepSplit) {
@@ -1035,7 +1039,8 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             launchTiled<T, WIDE, IS_HELL, true>(stream, a, tune->xTileShape);
         else
             launchShape<T, WIDE, 1, IS_HELL, (sizeof(T) == 8 ? 8 : 4), true, kBlockThreads, 0, true>(stream, a);
-        launchDeep<T, WIDE, IS_HELL>(stream, a);
+        if (deepPossible)
+            launchDeep<T, WIDE, IS_HELL>(stream, a);
         return;
     }
     bool strips = false, autoTile = false;
