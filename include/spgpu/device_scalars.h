@@ -10,6 +10,7 @@
  *
  * Values are the SAME BITS as the host-scalar calls produce:
  *   spgpu?dotDevice     *result == what spgpu?dot returns (the same block partials, combined in the same fixed order);
+ *   spgpu?nrm2Device    *result == what spgpu?nrm2 returns;
  *   spgpu?axpbyDevice   z == what spgpu?axpby writes for alpha = *alpha, beta = *beta
  *                       (beta == NULL or *beta == 0: y is not read, z = alpha*x);
  *   spgpu?axpbyQuotDevice  the same with each coefficient given as a quotient of two device scalars,
@@ -29,6 +30,10 @@ extern "C" {
 
 void spgpuSdotDevice(spgpuHandle_t handle, __device float* result, int n, const __device float* a, const __device float* b);
 void spgpuDdotDevice(spgpuHandle_t handle, __device double* result, int n, const __device double* a, const __device double* b);
+
+/* *result == what spgpu?nrm2 returns (the residual norm of a solver without a host round trip). */
+void spgpuSnrm2Device(spgpuHandle_t handle, __device float* result, int n, const __device float* a);
+void spgpuDnrm2Device(spgpuHandle_t handle, __device double* result, int n, const __device double* a);
 
 void spgpuSaxpbyDevice(spgpuHandle_t handle, __device float* z, int n, const __device float* beta, const __device float* y,
                        const __device float* alpha, const __device float* x);

@@ -233,9 +233,10 @@ spgpuMmUnfoldD = _decl("spgpuMmUnfoldD", None, [ptr, ptr, ptr, ptr, ptr, ptr, i3
 
 
 # ---- device_scalars.h (new: results and coefficients in device memory, graph-capturable) ---------------------
-dot_device, axpby_device, axpby_quot_device, div_device = {}, {}, {}, {}
+dot_device, axpby_device, axpby_quot_device, div_device, nrm2_device = {}, {}, {}, {}, {}
 for _L in "SD":
     dot_device[_L] = _decl(f"spgpu{_L}dotDevice", None, [Handle, ptr, i32, ptr, ptr])
+    nrm2_device[_L] = _decl(f"spgpu{_L}nrm2Device", None, [Handle, ptr, i32, ptr])
     axpby_device[_L] = _decl(f"spgpu{_L}axpbyDevice", None, [Handle, ptr, i32, ptr, ptr, ptr, ptr])
     axpby_quot_device[_L] = _decl(f"spgpu{_L}axpbyQuotDevice", None, [Handle, ptr, i32, ptr, ptr, ptr, ptr, ptr, i32, ptr])
     div_device[_L] = _decl(f"spgpu{_L}divDevice", None, [Handle, ptr, ptr, ptr, i32])

@@ -371,6 +371,31 @@ static void dotToDevice(spgpuHandle_t handle, T* result, int n, const T* a, cons
     spgpuDebugCheck(handle, "dotDevice");
 }
 
+/* nrm2 with the result left in device memory: first stage and grid of spgpu?nrm2, the square root taken by the final
+ * stage's lane. */
+template <typename T>
+static void nrm2ToDevice(spgpuHandle_t handle, T* result, int n, const T* a)
+{
+    hipStream_t s = handle->currentStream;
+    T* dev = static_cast<T*>(spgpuPrivate(handle)->reduceScratch);
+    long long blocks = 0;
+    if (n > 0) {
+        constexpr int WIDE = 16 / (int)sizeof(T);
+        const bool wide = WIDE > 1 && ((uintptr_t)a % 16 == 0);
+        const long long work = wide ? ((long long)n + WIDE - 1) / WIDE : n;
+        blocks = (work + kL1Threads * kL1Unroll - 1) / (kL1Threads * kL1Unroll);
+        if (blocks > SPGPU_REDUCE_MAX_BLOCKS)
+            blocks = SPGPU_REDUCE_MAX_BLOCKS;
+        const dim3 grid((unsigned)blocks, 1);
+        if (wide)
+            hipLaunchKernelGGL((reduceKernel<T, WIDE, kNrm2>), grid, dim3(kL1Threads), 0, s, dev, n, a, (const T*)nullptr, 0ll);
+        else
+            hipLaunchKernelGGL((reduceKernel<T, 1, kNrm2>), grid, dim3(kL1Threads), 0, s, dev, n, a, (const T*)nullptr, 0ll);
+    }
+    hipLaunchKernelGGL((reduceFinalKernel<T, kNrm2, true>), dim3(1), dim3(kWave), 0, s, result, dev, (int)blocks);
+    spgpuDebugCheck(handle, "nrm2Device");
+}
+
 template <typename T>
 static void axpbyFromDevice(spgpuHandle_t handle, T* z, int n, int hasBeta, const T* betaNum, const T* betaDen, const T* y,
                             const T* alphaNum, const T* alphaDen, int negateAlpha, const T* x)
@@ -724,6 +749,8 @@ void spgpuIsetscal(spgpuHandle_t h, int first, int last, int baseIndex, int val,
 /* ---- include/spgpu/device_scalars.h ---- */
 void spgpuSdotDevice(spgpuHandle_t h, float* result, int n, const float* a, const float* b) { dotToDevice<float>(h, result, n, a, b); }
 void spgpuDdotDevice(spgpuHandle_t h, double* result, int n, const double* a, const double* b) { dotToDevice<double>(h, result, n, a, b); }
+void spgpuSnrm2Device(spgpuHandle_t h, float* result, int n, const float* a) { nrm2ToDevice<float>(h, result, n, a); }
+void spgpuDnrm2Device(spgpuHandle_t h, double* result, int n, const double* a) { nrm2ToDevice<double>(h, result, n, a); }
 void spgpuSaxpbyDevice(spgpuHandle_t h, float* z, int n, const float* beta, const float* y, const float* alpha, const float* x)
 { axpbyFromDevice<float>(h, z, n, beta != nullptr, beta, nullptr, y, alpha, nullptr, 0, x); }
 void spgpuSaxpbyQuotDevice(spgpuHandle_t h, float* z, int n, const float* betaNum, const float* betaDen, const float* y,

@@ -81,7 +81,10 @@ template <int MODE, typename Acc> static inline Acc finalOrder(const Acc* partia
     return lane[0];
 }
 
-template <typename Acc, int MODE>
+__device__ inline float squareRoot(float v) { return __builtin_sqrtf(v); }
+__device__ inline double squareRoot(double v) { return __builtin_sqrt(v); }
+
+template <typename Acc, int MODE, bool ROOT = false>
 __global__ __launch_bounds__(kWave) void reduceFinalKernel(Acc* result, const Acc* partials, int blocks)
 {
     Acc mine[kFinalPerLane];
@@ -97,8 +100,12 @@ __global__ __launch_bounds__(kWave) void reduceFinalKernel(Acc* result, const Ac
 #pragma unroll
     for (int m = 1; m < kWave; m <<= 1)
         sum = combine<MODE>(sum, laneXor(sum, m));
-    if (threadIdx.x == 0)
-        *result = sum;
+    if (threadIdx.x == 0) {
+        if constexpr (ROOT)
+            *result = squareRoot(sum); /* nrm2: sqrt of the unscaled sum of squares (dnrm2.cu:146) */
+        else
+            *result = sum;
+    }
 }
 
 } // namespace spgpu

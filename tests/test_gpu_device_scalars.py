@@ -31,6 +31,22 @@ def test_dot_device_equals_dot(gpu, letter, n, offset):
 
 
 @pytest.mark.parametrize("letter", "SD")
+@pytest.mark.parametrize("n,offset", [(1, 0), (1000, 0), (4097, 1), (1 << 20, 0), (3_000_001, 0)])
+def test_nrm2_device_equals_nrm2(gpu, letter, n, offset):
+    import torch
+    from spgpu_amd import capi, formats, synth
+    a = formats.to_device(synth.values_for(letter, 1, n + offset))[offset:]
+    out = torch.zeros(1, dtype=a.dtype, device="cuda:0")
+    capi.nrm2_device[letter](gpu, _p(out), n, _p(a))
+    want = capi.nrm2[letter](gpu, n, _p(a))
+    got = out.cpu().numpy()[0]
+    assert np.asarray(got).tobytes() == np.asarray(want, dtype=got.dtype).tobytes()
+    capi.nrm2_device[letter](gpu, _p(out), 0, _p(a))
+    torch.cuda.synchronize()
+    assert out.cpu().numpy()[0] == 0
+
+
+@pytest.mark.parametrize("letter", "SD")
 def test_axpby_and_div_device_equal_host_scalar_calls(gpu, letter):
     import torch
     from spgpu_amd import capi, formats, synth

@@ -1,2 +1,2 @@
 cd /root/repo
-timeout -k 10 900 python -m pytest tests/test_gpu_oell_device.py tests/test_gpu_fuzz.py tests/test_gpu_c_harness.py tests/test_gpu_spmv.py tests/test_gpu_f3.py -x -q 2>&1 | tail -4
+timeout -k 10 600 python -m pytest tests/test_gpu_device_scalars.py tests/test_gpu_level1.py tests/test_gpu_level1_rest.py tests/test_gpu_fused_solver.py -x -q 2>&1 | tail -4
