@@ -1,2 +1,3 @@
 cd /root/repo
-timeout -k 10 600 python -m pytest tests/test_gpu_device_scalars.py tests/test_gpu_level1.py tests/test_gpu_level1_rest.py tests/test_gpu_fused_solver.py -x -q 2>&1 | tail -4
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 &&
+timeout -k 10 600 python bench.py > gpurun_out/bench_r02f.json 2> gpurun_out/bench_r02f.err; echo "bench rc $?"
