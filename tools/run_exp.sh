@@ -1,3 +1,6 @@
 cd /root/repo
-timeout -k 10 1100 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 &&
-timeout -k 10 600 python bench.py > gpurun_out/bench_r02f.json 2> gpurun_out/bench_r02f.err; echo "bench rc $?"
+export EXP_PATTERNS=band,near EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256
+for i in 1 2 3; do
+EXP_FORMS=ragged0,ragged0n,ragged0,ragged0n timeout -k 10 300 python tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep "^D " | cut -c1-118
+done
+EXP_FORMS=ragged0,ragged0n,ragged0,ragged0n timeout -k 10 300 python tools/exp_tile.py D 10000000 mild 2>&1 | grep "^D " | grep -v plain | cut -c1-118
