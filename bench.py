@@ -642,20 +642,36 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
     plans, comm = {}, None
     if driver == "c":
         ok = 1.0
+
+        def everyone(mine):
+            """True iff `mine` is true on every rank (one all_reduce: called by all ranks at the same point)."""
+            if not distributed:
+                return bool(mine)
+            flag = torch.tensor([1.0 if mine else 0.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return float(flag.item()) > 0.5
+
         try:
             if distributed:
-                ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+                # Every step that could fail on ONE rank is followed by an agreement of all ranks before the next
+                # collective: a rank that raised on its own would leave the others waiting in a collective for ever.
+                if not everyone(capi.spgpuCommAvailable()):
+                    raise RuntimeError("RCCL cannot be loaded on every rank")
+                ident = torch.zeros(129, dtype=torch.uint8, device=dev)       # 128 bytes of id + "valid"
                 if rank == 0:
                     raw = (C.c_char * 128)()
-                    if capi.spgpuCommGetUniqueId(raw) != capi.SPGPU_SUCCESS:
-                        raise RuntimeError("spgpuCommGetUniqueId failed")
-                    ident.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
-                dist.broadcast(ident, 0)
+                    if capi.spgpuCommGetUniqueId(raw) == capi.SPGPU_SUCCESS:
+                        ident[:128].copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+                        ident[128] = 1
+                dist.broadcast(ident, 0)                                      # always, valid or not
                 torch.cuda.synchronize()
-                raw = (C.c_char * 128).from_buffer_copy(bytes(ident.cpu().numpy().tobytes()))
+                host_ident = ident.cpu().numpy()
+                if host_ident[128] != 1:
+                    raise RuntimeError("spgpuCommGetUniqueId failed on rank 0")
+                raw = (C.c_char * 128).from_buffer_copy(bytes(host_ident[:128].tobytes()))
                 comm = C.c_void_p()
-                if capi.spgpuCommInitRank(C.byref(comm), world, raw, rank) != capi.SPGPU_SUCCESS:
-                    raise RuntimeError("spgpuCommInitRank failed")
+                if not everyone(capi.spgpuCommInitRank(C.byref(comm), world, raw, rank) == capi.SPGPU_SUCCESS):
+                    raise RuntimeError("spgpuCommInitRank failed on some rank")
             first_rows = (C.c_longlong * (world + 1))(*[r * rows_local for r in range(world + 1)])
             own_block = capi.hell_block(own, L)
             rest_block = capi.hell_block(rest, L) if rest is not None else None
@@ -664,16 +680,13 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                 plan = capi.ShardedPlan()
                 status = capi.spgpuDhellspmmShardedCreate(C.byref(plan), handle, comm, rank, world, first_rows, C.byref(own_block),
                                                           C.byref(rest_block) if rest_block is not None else None, k, kind)
-                if status != capi.SPGPU_SUCCESS:
-                    raise RuntimeError(f"spgpuDhellspmmShardedCreate({name}) returned {status}")
-                plans[name] = plan
-        except Exception as error:  # noqa: BLE001 - any failure of the set-up: every rank falls back together
+                if status == capi.SPGPU_SUCCESS:
+                    plans[name] = plan
+                if not everyone(status == capi.SPGPU_SUCCESS):
+                    raise RuntimeError(f"spgpuDhellspmmShardedCreate({name}) returned {status} (or failed on another rank)")
+        except Exception as error:  # noqa: BLE001 - raised by every rank at the same point (see `everyone`)
             print(f"rank {rank}: C driver set-up failed ({error!r}); falling back to the torch.distributed driver", file=sys.stderr, flush=True)
             ok = 0.0
-        if distributed:
-            flag = torch.tensor([ok], device=dev, dtype=torch.float64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = float(flag.item())
         if ok < 0.5:
             for plan in plans.values():
                 capi.spgpuDhellspmmShardedDestroy(plan)
@@ -859,6 +872,11 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                       allgather_step_ms=round(t_step_allgather * 1e3, 4) if t_step_allgather else None,
                       allgather_step_gflops_total=round(flops_total / t_step_allgather * 1e-9, 1) if t_step_allgather else None),
             parity=parity, cpu_baseline=None)
+        if world > 1:
+            out["scaling_base"] = ("this line is the row-sharded SpMM of BASELINE configs[4]; its N = 1 point is `spmm_1gpu.value` of the "
+                                   "`--gpus 1` line (same 5 M rows x 32 x 16 rhs per GPU, no exchange), NOT that line's `value`, which is the "
+                                   "single-GPU SpMV of configs[1] -- single-vector SpMV does not shard (replicas only, DESIGN.md section 6); "
+                                   "`spmm.compute_only_gflops_total` here is the same products on all ranks without the exchange")
         out["config"]["driver"] = ("C ABI (spgpuDhellspmmShardedStep: packing kernel, RCCL and products issued by libspgpu.so)" if driver == "c"
                                    else "torch.distributed collectives + C-ABI products")
         if t_step_allgather:

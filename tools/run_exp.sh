@@ -1,6 +1,5 @@
 cd /root/repo
-export EXP_PATTERNS=band,near EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256
-for i in 1 2 3; do
-EXP_FORMS=ragged0,ragged0n,ragged0,ragged0n timeout -k 10 300 python tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep "^D " | cut -c1-118
-done
-EXP_FORMS=ragged0,ragged0n,ragged0,ragged0n timeout -k 10 300 python tools/exp_tile.py D 10000000 mild 2>&1 | grep "^D " | grep -v plain | cut -c1-118
+timeout -k 10 600 python -m pytest tests/test_gpu_bench_rehearsal.py tests/test_gpu_sharded_c.py -x -q 2>&1 | tail -3 &&
+timeout -k 10 300 python bench.py --workload spmm --steps 20 --warmup 3 --no-extras 2>gpurun_out/spmm1.err | tail -1 | cut -c1-400 &&
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --workload spmm --steps 20 --warmup 3 --no-extras 2>gpurun_out/spmm1t.err | tail -1 | cut -c1-400
+tail -3 gpurun_out/spmm1t.err
