@@ -59,7 +59,8 @@ typedef struct spgpuHellBlockD {
 typedef struct spgpuShardedSpmmPlan* spgpuShardedSpmm_t;
 
 /* ---- RCCL through dlopen: enough for a caller that does not want <rccl/rccl.h> itself -------------------------- */
-/* 1 if the RCCL library could be opened. */
+/* 1 if the RCCL library could be opened: the copy already in the process (torch ships one), else the system's;
+ * the environment variable SPGPU_RCCL_LIBRARY names a particular one. */
 int spgpuCommAvailable(void);
 /* 128 bytes (ncclUniqueId) from ncclGetUniqueId; hand them to the other ranks by any means. */
 spgpuStatus_t spgpuCommGetUniqueId(__host void* id128);

@@ -50,6 +50,11 @@ static bool loadRccl()
         /* the copy the process already uses first (torch ships its own librccl.so), then the system's */
         const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         void* lib = nullptr;
+        /* SPGPU_RCCL_LIBRARY: a particular build (or, in the tests, an in-process stand-in that lets several ranks run as
+         * threads on one GPU: tests/mock_rccl.c) */
+        const char* named = getenv("SPGPU_RCCL_LIBRARY");
+        if (named && named[0])
+            lib = dlopen(named, RTLD_NOW | RTLD_GLOBAL);
         for (int pass = 0; pass < 2 && !lib; ++pass)
             for (const char* name : names) {
                 lib = dlopen(name, (pass == 0 ? RTLD_NOLOAD : 0) | RTLD_NOW | RTLD_GLOBAL);

@@ -1,12 +1,13 @@
 """GPU: the row-sharded SpMM driver in C (include/spgpu/sharded.h) on the one GPU of the test box.
 
-One rank with a real RCCL communicator (ncclCommInitRank, world 1; RCCL refuses two ranks on one device, so the
-send/recv legs between DIFFERENT ranks cannot run here -- they are exercised by the driver's multi-GPU bench run,
-and their Python twin runs under gloo in tests/test_sharded_gloo.py).  What this covers: the library opens RCCL by
-dlopen, the needed-rows set-up on the device (sorted unique columns, renumbering, the cut at block boundaries, the
-request lists), the packing kernel, the stream ordering of a step, both exchanges, against the oracle's product of
+One rank with a real RCCL communicator (ncclCommInitRank, world 1; RCCL refuses two ranks on one device): the library
+opens RCCL by dlopen, the needed-rows set-up on the device (sorted unique columns, renumbering, the cut at block
+boundaries, the request lists), the packing kernel, the stream ordering of a step, both exchanges, against the oracle's
+product of the UNSPLIT matrix.  And 2 ... 8 ranks as THREADS over an in-process stand-in for RCCL (tests/mock_rccl.c):
+the send/recv legs between different ranks, equal and unequal blocks, each rank's rows against the oracle's product of
 the UNSPLIT matrix."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -139,3 +140,37 @@ def test_create_rejects_bad_arguments(gpu):
     bad = (C.c_longlong * 2)(0, 3000)
     assert capi.spgpuDhellspmmShardedCreate(C.byref(plan), gpu, None, 0, 1, bad, C.byref(ob), None, 4, 0) != capi.SPGPU_SUCCESS
     assert not plan
+
+
+# ---- world > 1 on one GPU: the ranks as threads over an in-process stand-in for RCCL ------------------------------
+@pytest.fixture(scope="module")
+def mock_rccl(tmp_path_factory):
+    """tests/mock_rccl.c built with gcc: rendezvous + device copies ordered by events, and checks that every receive
+    meets a send of its size (what real RCCL would turn into a hang)."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    lib = str(tmp_path_factory.mktemp("mock") / "libmock_rccl.so")
+    cmd = ["gcc", "-O1", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(here, "mock_rccl.c"),
+           "-L/opt/rocm/lib", "-lamdhip64", "-lpthread", "-Wl,-rpath,/opt/rocm/lib", "-o", lib]
+    done = subprocess.run(cmd, capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr
+    return lib
+
+
+@pytest.mark.parametrize("world,pattern,exchange,shape", [
+    (2, "banded", "needed", "even"), (2, "banded", "allgather", "even"),
+    (3, "window", "needed", "uneven"), (3, "window", "allgather", "uneven"),      # unequal blocks: grouped send/recv all-gather
+    (4, "random", "needed", "even"), (4, "banded", "needed", "uneven"),
+    (8, "banded", "needed", "even"), (8, "random", "allgather", "even"),          # the size of the driver's scale run
+])
+def test_many_ranks_as_threads(mock_rccl, world, pattern, exchange, shape):
+    """The C driver with world > 1: who needs which rows, the request exchange at Create, the packed sends and receives
+    of every step, the stream ordering -- each rank's rows against the oracle's product of the whole matrix.  The
+    communication library is the stand-in (no second GPU here); everything else is the code the multi-GPU run executes."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SPGPU_RCCL_LIBRARY=mock_rccl)
+    run = subprocess.run([sys.executable, os.path.join(here, "run_sharded_ranks.py"), str(world), pattern, exchange, shape],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0 and "ALL RANKS OK" in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]

@@ -1,5 +1,4 @@
 cd /root/repo
-timeout -k 10 600 python -m pytest tests/test_gpu_bench_rehearsal.py tests/test_gpu_sharded_c.py -x -q 2>&1 | tail -3 &&
-timeout -k 10 300 python bench.py --workload spmm --steps 20 --warmup 3 --no-extras 2>gpurun_out/spmm1.err | tail -1 | cut -c1-400 &&
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --workload spmm --steps 20 --warmup 3 --no-extras 2>gpurun_out/spmm1t.err | tail -1 | cut -c1-400
-tail -3 gpurun_out/spmm1t.err
+gcc -O1 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/mock_rccl.c -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,/opt/rocm/lib -o /tmp/libmock_rccl.so
+SPGPU_RCCL_LIBRARY=/tmp/libmock_rccl.so timeout -k 10 300 python tests/run_sharded_ranks.py 8 banded needed uneven 2>&1 | grep -v amdgpu.ids
+SPGPU_RCCL_LIBRARY=/tmp/libmock_rccl.so timeout -k 10 300 python tests/run_sharded_ranks.py 3 random allgather uneven 2>&1 | grep -v amdgpu.ids
