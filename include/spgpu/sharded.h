@@ -7,7 +7,9 @@
  * operation (packing, RCCL, the products) issued from here -- no Python, no torch on the path.
  *
  * Model: one rank per GPU (one process per GPU with ncclCommInitRank, or one process driving several devices
- * with ncclCommInitAll -- both work, a rank is a (handle, communicator) pair).  Rows of A, Y, Z and X are cut
+ * with ncclCommInitAll -- both work, a rank is a (handle, communicator) pair; in one process every rank needs a
+ * host thread of its own: Create with SPGPU_EXCHANGE_NEEDED and every Step are collectives that a single thread
+ * calling them rank after rank would never complete -- tests/run_sharded_ranks.py drives 8 ranks that way).  Rows of A, Y, Z and X are cut
  * into contiguous blocks, boundaries multiples of the hack size; rank r owns rows
  * [blockFirstRow[r], blockFirstRow[r+1]).  The caller has cut its row block of A by column ownership:
  *     own   entries whose column lies in the rank's own block, columns REBASED to that block (they index X_local)
