@@ -3,7 +3,15 @@
 patterns between "consecutive" and "scattered", and on power-law row lengths before and after ordering the rows by
 length (spgpuOellOrderDevice).  Every timing is followed by an oracle check of three row windows.
 
-    python tools/exp_tile.py [D|S] [rows] [cases: uniform,powerlaw]
+    python tools/exp_tile.py [D|S] [rows] [cases: uniform,mild,powerlaw]
+
+Environment: EXP_FORMS = comma list of  auto | gather | strips | tileN (x-tile shape N) | raggedN (the kernel for ordered
+rows, workgroup shape N) | raggedg (the same with plain gathers); a suffix xR (ragged0x4) runs it with R consecutive row
+blocks per XCD.  EXP_PATTERNS = near,band,random (power-law) or near2048,near512,window,banded (uniform);
+EXP_ORDERS = window:longRows pairs (2048:256,...); EXP_ONLY_WINDOWED=1 skips the plain and globally sorted layouts;
+EXP_WINDOWS_FOR_ALL=1 runs the windowed orders on scattered columns too; EXP_ALIGNED=1 orders the rows on the host
+with windows counted among the short rows (one window = one workgroup; measured slower, DESIGN.md section 3.1);
+EXP_DROP_RIDX=1 runs the ordered matrix without its row order (timing only).  SPGPU_* knobs pass through.
 """
 import ctypes as C
 import os

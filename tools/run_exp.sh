@@ -1,4 +1,6 @@
+#!/bin/bash
+# Scratch wrapper for one-off runs on the GPU box:  gpurun -- 'bash tools/run_exp.sh'
+# (edit the commands below; everything that is kept lives in tools/*.py and profiles/)
 cd /root/repo
-gcc -O1 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/mock_rccl.c -L/opt/rocm/lib -lamdhip64 -lpthread -Wl,-rpath,/opt/rocm/lib -o /tmp/libmock_rccl.so
-SPGPU_RCCL_LIBRARY=/tmp/libmock_rccl.so timeout -k 10 300 python tests/run_sharded_ranks.py 8 banded needed uneven 2>&1 | grep -v amdgpu.ids
-SPGPU_RCCL_LIBRARY=/tmp/libmock_rccl.so timeout -k 10 300 python tests/run_sharded_ranks.py 3 random allgather uneven 2>&1 | grep -v amdgpu.ids
+export EXP_PATTERNS=band,near EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256 EXP_FORMS=ragged0
+timeout -k 10 300 python tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep "^D "
