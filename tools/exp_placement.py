@@ -52,17 +52,14 @@ for base in (0,):
         rP.copy_(h["rP"][:slots])
         torch.cuda.synchronize()
         print(f"  base +{base:>8}  gap {gap:>9}  {timed(cM, rP):.4f} ms", flush=True)
-# fresh allocations of every array (a dummy block of changing size in front shifts them all)
-import random
-random.seed(1)
-keep = []
-for trial in range(10):
-    keep.append(torch.empty(random.randrange(1, 400) << 20, dtype=torch.uint8, device="cuda"))
-    hh = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in h.items()}
-    x2, z2 = x.clone(), torch.zeros_like(z)
-    torch.cuda.synchronize()
-    call = lambda: capi.hellspmv["D"](handle, p(z2), None, 1.0, p(hh["cM"]), p(hh["rP"]), 32, p(hh["hack_offsets"]), p(hh["rS"]),
-                                      p(hh["rIdx"]), 32, n, p(x2), 0.0, 0)
+# z (then x) at different offsets inside one 512 MiB buffer, everything else fixed
+pool = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+offsets = [0, 128, 4096, 65536, 1 << 20, 2 << 20, 3 << 20, 5 << 20, 16 << 20, 17 << 20, 33 << 20, 64 << 20, 96 << 20, 130 << 20, 200 << 20, 256 << 20]
+
+
+def timed_with(xv, zv):
+    call = lambda: capi.hellspmv["D"](handle, p(zv), None, 1.0, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]), p(h["rIdx"]),
+                                      32, n, p(xv), 0.0, 0)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(stream):
         for _ in range(3):
@@ -72,6 +69,15 @@ for trial in range(10):
             call()
         b.record(stream)
     b.synchronize()
-    print(f"  fresh allocations {trial}: cM {hh['cM'].data_ptr():#x} x {x2.data_ptr():#x} z {z2.data_ptr():#x}  {a.elapsed_time(b) / 20:.4f} ms", flush=True)
-    del hh, x2, z2
+    return a.elapsed_time(b) / 20
+
+
+for what in ("z", "x"):
+    for off in offsets:
+        view = pool[off:off + n * 8].view(torch.float64)
+        if what == "x":
+            view.copy_(x)
+        torch.cuda.synchronize()
+        t = timed_with(view if what == "x" else x, view if what == "z" else z)
+        print(f"  {what} at pool + {off:>10} ({view.data_ptr():#x})  {t:.4f} ms", flush=True)
 capi.spgpuDestroy(handle)
