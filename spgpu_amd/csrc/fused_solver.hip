@@ -98,13 +98,31 @@ __device__ inline void rowSums(const FusedSpmvArgs<T>& a, long long row, bool li
                 column[t] = in ? a.rP[s] : a.baseIndex;
             }
         }
+        /* neighbouring rows of a stencil or a band name neighbouring columns: then the VEC values of x are ONE load
+         * (wavefront-uniform choice; the same values either way) */
+        bool strip = PACKED && VEC > 1;
+        if constexpr (PACKED && VEC > 1) {
+            bool mine = column[0] - a.baseIndex >= 0;
 #pragma unroll
-        for (int t = 0; t < VEC; ++t) {
-            const int col = column[t] - a.baseIndex;
-            const bool use = k < len[t] && col >= 0;
-            const T xv = a.x[use ? col : 0];
-            if (use)
-                sum[t] = mulAdd(value[t], xv, sum[t]);
+            for (int t = 0; t < VEC; ++t)
+                mine = mine && k < len[t] && column[t] == column[0] + t;
+            strip = __ballot(!mine && k < longest) == 0ull;
+        }
+        if (strip) {
+            const Pack<T, VEC> xs = loadPackElementAligned<T, VEC>(a.x + (k < longest ? column[0] - a.baseIndex : 0));
+#pragma unroll
+            for (int t = 0; t < VEC; ++t)
+                if (k < len[t])
+                    sum[t] = mulAdd(value[t], xs.v[t], sum[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                const int col = column[t] - a.baseIndex;
+                const bool use = k < len[t] && col >= 0;
+                const T xv = a.x[use ? col : 0];
+                if (use)
+                    sum[t] = mulAdd(value[t], xv, sum[t]);
+            }
         }
     }
 }
