@@ -34,8 +34,8 @@ void spgpuTuningReload(void);
 
 /*
  * Per-handle hint: how the ELL/HELL SpMV kernels fetch x (no counterpart in the reference, whose only per-call hint
- * is avgNnzPerRow, hell.h:45-59).  Every form computes the same values; for one kernel shape the bits are the same
- * too (the order in which a row's products are added does not depend on the form).
+ * is avgNnzPerRow, hell.h:45-59).  Every form computes the same values; AUTO, GATHER, STRIPS and XTILE also the same
+ * bits (the order in which a row's products are added does not depend on the form).
  *
  *   AUTO    the library decides per matrix: sample wavefronts of every launch report what they saw (consecutive
  *           columns in neighbouring rows / columns inside a window that fits an LDS tile / scattered) and the next
@@ -47,6 +47,14 @@ void spgpuTuningReload(void);
  *           (columns near the diagonal but not consecutive; length-sorted rows used through rIdx); entries outside
  *           the tile are gathered from global memory.
  *
+ *   SWEEP   (never chosen by AUTO) for matrices whose columns are scattered over all of x but ascend inside a row: a
+ *           lane carries 32 rows (16 for complex fp64) through the slab columns in step, so that at any moment the rows
+ *           in flight gather from the same quantile of x and meet in L2 (10 M x 32 scattered, fp64: 4.5 ms against
+ *           5.85).  A row's products are added in ascending k -- the reference's one-thread-per-row order
+ *           (hell_spmv_base_template.cuh:104-215) -- which is NOT the bit pattern of the other forms for fp32, for complex
+ *           fp64 and on rows short enough to engage the whole-wave tail; without rIdx only (with rIdx: as AUTO).  On
+ *           matrices with locality between neighbouring rows this form is several times SLOWER than the others.
+ *
  * The hint applies to every later SpMV call on the handle, from any thread; SPGPU_X_STRIPS / SPGPU_X_TILE in the
  * environment override it.
  */
@@ -54,9 +62,10 @@ void spgpuTuningReload(void);
 #define SPGPU_SPMV_FORM_GATHER 1
 #define SPGPU_SPMV_FORM_STRIPS 2
 #define SPGPU_SPMV_FORM_XTILE  3
+#define SPGPU_SPMV_FORM_SWEEP  4
 void spgpuSetSpmvForm(spgpuHandle_t handle, int form);
 int spgpuGetSpmvForm(spgpuHandle_t handle);
-/* Diagnostic: the form (GATHER / STRIPS / XTILE) the most recent ELL/HELL SpMV call on this handle was launched in. */
+/* Diagnostic: the form (GATHER / STRIPS / XTILE / SWEEP) the most recent ELL/HELL SpMV call on this handle was launched in. */
 int spgpuGetLastSpmvForm(spgpuHandle_t handle);
 
 #ifdef __cplusplus

@@ -250,7 +250,7 @@ for _L in "SD":
 
 
 # ---- tuning.h: per-handle kernel-form hint ---------------------------------------------------------------------
-FORM_AUTO, FORM_GATHER, FORM_STRIPS, FORM_XTILE = range(4)
+FORM_AUTO, FORM_GATHER, FORM_STRIPS, FORM_XTILE, FORM_SWEEP = range(5)
 spgpuSetSpmvForm = _decl("spgpuSetSpmvForm", None, [Handle, i32])
 spgpuGetSpmvForm = _decl("spgpuGetSpmvForm", i32, [Handle])
 spgpuGetLastSpmvForm = _decl("spgpuGetLastSpmvForm", i32, [Handle])

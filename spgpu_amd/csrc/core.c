@@ -196,7 +196,7 @@ spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, SpgpuDeepList* list)
 /* ---- per-handle kernel-form hint (include/spgpu/tuning.h) ---- */
 void spgpuSetSpmvForm(spgpuHandle_t pHandle, int form)
 {
-    if (form < SPGPU_SPMV_FORM_AUTO || form > SPGPU_SPMV_FORM_XTILE)
+    if (form < SPGPU_SPMV_FORM_AUTO || form > SPGPU_SPMV_FORM_SWEEP)
         form = SPGPU_SPMV_FORM_AUTO;
     __atomic_store_n(&spgpuPrivate(pHandle)->spmvForm, form, __ATOMIC_RELAXED);
 }

@@ -849,6 +849,96 @@ __global__ __launch_bounds__(kBlockThreads) void deepFinishKernel(const SlabArgs
     }
 }
 
+/*
+ * SWEEP form (include/spgpu/tuning.h; chosen by the caller, never by AUTO): for matrices whose columns are scattered over
+ * all of x but ascend inside a row.  A lane owns PACKS packs of VEC neighbouring rows (32 rows for 4- and 8-byte elements)
+ * and carries all of them through the slab columns in step; the grid is small enough to be resident at once and walks
+ * the rows with a tile stride.  At any moment the rows in flight are at about the same k, i.e. they gather from about the
+ * same quantile of x, and meet in L2: 10 M x 32 scattered, fp64: L2 hits 22 M -> 54 M of 320 M gathers, 5.85 -> 4.5 ms.
+ * A row's products are added in ascending k (orc_?hellspmv / orc_?ellspmv with one phase), the reference's
+ * one-thread-per-row order (hell_spmv_base_template.cuh:104-215).  No LDS; coefficient and index streams non-temporal.
+ */
+template <typename T, int VEC, int PACKS, bool IS_HELL, bool HAS_BETA>
+__global__ __launch_bounds__(kBlockThreads) void sweepSpmvKernel(const SlabArgs<T> a)
+{
+    const long long packs = ((long long)a.rows + VEC - 1) / VEC;
+    constexpr long long TILE = (long long)kBlockThreads * PACKS;
+    for (long long base = (long long)blockIdx.x * TILE; base < packs; base += (long long)gridDim.x * TILE) {
+        T sums[PACKS][VEC];
+        int len[PACKS][VEC];
+        long long slot[PACKS];
+        int longest = 0;
+#pragma unroll
+        for (int u = 0; u < PACKS; ++u) {
+            const long long row = (base + u * kBlockThreads + threadIdx.x) * VEC;
+            slot[u] = 0;
+            if (row < a.rows) {
+                if constexpr (IS_HELL) {
+                    const unsigned r0 = (unsigned)row, hs = (unsigned)a.hackSize;
+                    const unsigned hack = r0 / hs;
+                    slot[u] = (long long)a.hackOffsets[hack] + (r0 - hack * hs);
+                } else {
+                    slot[u] = row;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < VEC; ++t) {
+                sums[u][t] = zeroOf<T>();
+                len[u][t] = row + t < a.rows ? (a.rS ? a.rS[row + t] : a.maxNnz) : 0;
+                longest = len[u][t] > longest ? len[u][t] : longest;
+            }
+        }
+        for (int k = 0; k < longest; ++k) {
+            Pack<T, VEC> v[PACKS];
+            Pack<int, VEC> c[PACKS];
+#pragma unroll
+            for (int u = 0; u < PACKS; ++u) {
+                bool any = false;
+#pragma unroll
+                for (int t = 0; t < VEC; ++t)
+                    any |= k < len[u][t];
+                if (any) {
+                    v[u] = loadPack<true, T, VEC>(a.cM + slot[u] + (long long)k * a.valStride);
+                    c[u] = loadPack<true, int, VEC>(a.rP + slot[u] + (long long)k * a.idxStride);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t)
+                        c[u].v[t] = a.baseIndex;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PACKS; ++u) {
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) {
+                    const int col = c[u].v[t] - a.baseIndex;
+                    const bool use = k < len[u][t] && col >= 0;
+                    const T xv = a.x[use ? col : 0];
+                    if (use)
+                        sums[u][t] = mulAdd(v[u].v[t], xv, sums[u][t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PACKS; ++u) {
+            const long long row = (base + u * kBlockThreads + threadIdx.x) * VEC;
+            if (a.wideIO && row + VEC <= a.rows) {
+                Pack<T, VEC> out, yv;
+                if constexpr (HAS_BETA)
+                    yv = loadPack<false, T, VEC>(a.y + row);
+#pragma unroll
+                for (int t = 0; t < VEC; ++t)
+                    out.v[t] = epilogue<HAS_BETA>(a.alpha, sums[u][t], a.beta, HAS_BETA ? yv.v[t] : zeroOf<T>());
+                storePack<T, VEC>(a.z + row, out);
+            } else {
+#pragma unroll
+                for (int t = 0; t < VEC; ++t)
+                    if (row + t < a.rows)
+                        a.z[row + t] = epilogue<HAS_BETA>(a.alpha, sums[u][t], a.beta, HAS_BETA ? a.y[row + t] : zeroOf<T>());
+            }
+        }
+    }
+}
+
 #ifdef SPGPU_TRACE_BLOCKS
 __device__ unsigned long long* spgpuTraceBuffer;
 #endif
@@ -929,6 +1019,20 @@ static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
     }
 }
 
+/* SWEEP: 32 rows per lane (16 for 16-byte elements), at most 2 048 workgroups. */
+template <typename T, int VEC, bool IS_HELL>
+static void launchSweep(hipStream_t stream, const SlabArgs<T>& a)
+{
+    constexpr int PACKS = sizeof(T) == 16 ? 16 : 32 / VEC;
+    const long long packs = ((long long)a.rows + VEC - 1) / VEC;
+    long long blocks = (packs + (long long)kBlockThreads * PACKS - 1) / ((long long)kBlockThreads * PACKS);
+    blocks = blocks > 2048 ? 2048 : blocks;
+    if (isNotZero(a.beta))
+        hipLaunchKernelGGL((sweepSpmvKernel<T, VEC, PACKS, IS_HELL, true>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL((sweepSpmvKernel<T, VEC, PACKS, IS_HELL, false>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, a);
+}
+
 /* Right behind a DEEP kernel.  Fixed grids (the number of items is known on the device only): with nothing
  * registered both kernels read the header and leave. */
 constexpr int kDeepChunk = 64; /* measured: items of 32 / 64 / 128 columns and stages of 16 / 32 within 8 % -- the kernel is bound by the lines its gathers pull */
@@ -991,6 +1095,17 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         form = tune->xStrips ? SPGPU_SPMV_FORM_STRIPS : SPGPU_SPMV_FORM_GATHER;
     if (tune->xTile >= 0)
         form = tune->xTile ? SPGPU_SPMV_FORM_XTILE : (form == SPGPU_SPMV_FORM_XTILE ? SPGPU_SPMV_FORM_AUTO : form);
+    if (form == SPGPU_SPMV_FORM_SWEEP) {
+        /* the caller's choice for scattered columns that ascend inside a row; needs 16-byte slab accesses and no row order */
+        if (wideOk && !a.rIdx && tune->spmvVariant < 1) {
+            a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
+            a.feedback = nullptr;
+            spgpuNoteSpmvForm(handle, SPGPU_SPMV_FORM_SWEEP);
+            launchSweep<T, WIDE, IS_HELL>(stream, a);
+            return;
+        }
+        form = SPGPU_SPMV_FORM_AUTO;
+    }
     const bool tiled = form == SPGPU_SPMV_FORM_XTILE && (variant == 13 || variant == 21 || variant == 22);
     /* Deep split (see slabSpmvKernel, DEEP): on when the caller passes a row order -- rows ordered by length are what
      * one does to a ragged matrix, and then whole hacks are deep -- or when SPGPU_DEEP_SPLIT says so. */

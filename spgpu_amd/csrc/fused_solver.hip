@@ -338,107 +338,3 @@ void spgpuDaxpbyPairDotDevice(spgpuHandle_t h, double* result, int n, double* z1
 
 } // extern "C"
 
-/* ---- EXPERIMENT (tools/exp_fused_random.py): the row sweep of hellSpmvDotKernel without the dot and with PACKS packs
- * of rows per lane, to see what the number of rows a lane carries through the columns in step does on scattered columns */
-namespace spgpu {
-template <typename T, int VEC, int PACKS>
-__global__ __launch_bounds__(kL1Threads) void hellSpmvSweepKernel(FusedSpmvArgs<T> a)
-{
-    const long long packs = a.rows / VEC;
-    constexpr long long TILE = (long long)kL1Threads * PACKS;
-    for (long long base = (long long)blockIdx.x * TILE; base < packs; base += (long long)gridDim.x * TILE) {
-        T sums[PACKS][VEC];
-        int len[PACKS][VEC];
-        long long slot[PACKS];
-        int longest = 0;
-#pragma unroll
-        for (int u = 0; u < PACKS; ++u) {
-            const long long p = base + u * kL1Threads + threadIdx.x;
-            const long long row = p * VEC;
-            slot[u] = 0;
-#pragma unroll
-            for (int t = 0; t < VEC; ++t) {
-                sums[u][t] = zeroOf<T>();
-                len[u][t] = 0;
-            }
-            if (p < packs) {
-                const Pack<int, VEC> l = loadPack<false, int, VEC>(a.rS + row);
-                slot[u] = (long long)a.hackOffsets[row / a.hackSize] + row % a.hackSize;
-#pragma unroll
-                for (int t = 0; t < VEC; ++t) {
-                    len[u][t] = l.v[t];
-                    longest = l.v[t] > longest ? l.v[t] : longest;
-                }
-            }
-        }
-        for (int k = 0; k < longest; ++k) {
-            Pack<T, VEC> v[PACKS];
-            Pack<int, VEC> c[PACKS];
-#pragma unroll
-            for (int u = 0; u < PACKS; ++u) {
-                bool any = false;
-#pragma unroll
-                for (int t = 0; t < VEC; ++t)
-                    any |= k < len[u][t];
-                if (any) {
-                    v[u] = loadPack<true, T, VEC>(a.cM + slot[u] + (long long)k * a.hackSize);
-                    c[u] = loadPack<true, int, VEC>(a.rP + slot[u] + (long long)k * a.hackSize);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PACKS; ++u) {
-#pragma unroll
-                for (int t = 0; t < VEC; ++t) {
-                    const int col = c[u].v[t] - a.baseIndex;
-                    const bool use = k < len[u][t] && col >= 0;
-                    const T xv = a.x[use ? col : 0];
-                    if (use)
-                        sums[u][t] = mulAdd(v[u].v[t], xv, sums[u][t]);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PACKS; ++u) {
-            const long long p = base + u * kL1Threads + threadIdx.x;
-            if (p < packs) {
-                Pack<T, VEC> out;
-#pragma unroll
-                for (int t = 0; t < VEC; ++t)
-                    out.v[t] = epilogue<false>(a.alpha, sums[u][t], a.beta, zeroOf<T>());
-                storePack<T, VEC>(a.z + p * VEC, out);
-            }
-        }
-    }
-}
-} // namespace spgpu
-
-extern "C" void spgpuDhellspmvSweepExperiment(spgpuHandle_t h, double* z, const double* cM, const int* rP, int hackSize,
-                                               const int* hackOffsets, const int* rS, int rows, const double* x, int packsPerLane,
-                                               int blocks)
-{
-    using namespace spgpu;
-    FusedSpmvArgs<double> a;
-    a.partials = nullptr;
-    a.z = z;
-    a.y = nullptr;
-    a.cM = cM;
-    a.rP = rP;
-    a.hackOffsets = hackOffsets;
-    a.rS = rS;
-    a.x = x;
-    a.w = x;
-    a.alpha = 1.0;
-    a.beta = 0.0;
-    a.hackSize = hackSize;
-    a.rows = rows; /* rows % 2 == 0, hackSize % 2 == 0, aligned arrays assumed */
-    a.baseIndex = 0;
-    const dim3 grid((unsigned)blocks), block(kL1Threads);
-    hipStream_t s = h->currentStream;
-    switch (packsPerLane) {
-    case 2: hipLaunchKernelGGL((hellSpmvSweepKernel<double, 2, 2>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((hellSpmvSweepKernel<double, 2, 4>), grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((hellSpmvSweepKernel<double, 2, 8>), grid, block, 0, s, a); break;
-    case 16: hipLaunchKernelGGL((hellSpmvSweepKernel<double, 2, 16>), grid, block, 0, s, a); break;
-    default: break;
-    }
-}

@@ -1,6 +1,7 @@
 """GPU: seeded random cases through the C ABI against EXTENDED PRECISION (not the kernel-shaped oracle): every type, hack
 sizes that do and do not divide 32, both index bases, empty / short / power-law / a few huge rows, random / local / band
-columns, rIdx absent / a random permutation / the ordering by length, every x-fetch form, alpha and beta incl. 0, z == y.
+columns, rIdx absent / a random permutation / the ordering by length, every x-fetch form incl. SWEEP, alpha and beta incl. 0,
+z == y.
 The bound is north_star's: |z - z*| <= tol * (|alpha| * sum |a_ij x_j| + |beta y_i|), tol 1e-6 (fp64) / 1e-4 (fp32)."""
 import ctypes as C
 
@@ -116,7 +117,7 @@ def test_random_case_within_the_bound(gpu, seed):
         want, scale = _exact(case, x, y, alpha, beta)
     dx, dy = formats.to_device(x), formats.to_device(y)
     rI = formats.to_device(r_idx)
-    for form in (capi.FORM_AUTO, capi.FORM_GATHER, capi.FORM_STRIPS, capi.FORM_XTILE):
+    for form in (capi.FORM_AUTO, capi.FORM_GATHER, capi.FORM_STRIPS, capi.FORM_XTILE, capi.FORM_SWEEP):
         capi.spgpuSetSpmvForm(gpu, form)
         try:
             for fmt in ("hell", "ell"):

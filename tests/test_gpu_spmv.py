@@ -242,3 +242,34 @@ def test_handle_and_streams(gpu):
     ts.synchronize()
     assert torch.equal(z, 2.0 * a)
     capi.spgpuSetStream(gpu, None)
+
+
+@pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
+@pytest.mark.parametrize("fmt", ["hell", "ell"])
+@pytest.mark.parametrize("n,hack,base", [(1, 32, 0), (77, 32, 1), (5000, 64, 0), (40_003, 32, 0), (700_001, 32, 1)])
+def test_sweep_form_is_the_one_phase_order(gpu, letter, fmt, n, hack, base):
+    """SPGPU_SPMV_FORM_SWEEP (tuning.h): 32 rows per lane carried through the columns in step; a row's products added in
+    ascending k = the oracle with one phase, bit for bit; ragged rows incl. empty ones, rows not a multiple of the pack,
+    beta != 0, in place; and with a row order the hint falls back to the kernels for ordered rows."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    lengths = np.minimum(synth.power_law_lengths(n, mean=7.0, max_len=90, seed=n), n)
+    lengths[2::9] = 0
+    _, _, r, c, v = synth.random_rows_coo(n, n, lengths, seed=n + 1, letter=letter, base=base)
+    ell = formats.coo_to_ell(n, r, c, v, coo_base=base, ell_base=base)
+    hell = formats.ell_to_hell(ell, hack)
+    mat = formats.DeviceHell(hell) if fmt == "hell" else formats.DeviceEll(ell)
+    x, y = synth.values_for(letter, 3, n), synth.values_for(letter, 4, n)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_SWEEP)
+    try:
+        for alpha, beta, in_place in ((1.0, 0.0, False), (-0.75, 0.5, False), (2.0, 1.0, True)):
+            dz = dy.clone() if in_place else torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            mat.spmv(gpu, dz, dz if in_place else (dy if beta != 0 else None), alpha, dx, beta)
+            torch.cuda.synchronize()
+            assert capi.spgpuGetLastSpmvForm(gpu) == capi.FORM_SWEEP
+            oracle = O.hell_spmv if fmt == "hell" else O.ell_spmv
+            want = oracle(hell if fmt == "hell" else ell, x, y if beta != 0 else None, alpha, beta, phases=1)
+            assert dz.cpu().numpy().tobytes() == want.tobytes(), (alpha, beta, in_place)
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU box experiment: the fused SpMV + dot kernel (fused_solver.hip: 1 024 workgroups walking the rows with a tile
-stride, 8 rows per lane, no prefetch) against the default gather kernel on scattered columns.
+stride, 8 rows per lane, no prefetch) and the SWEEP form of the SpMV (32 rows per lane) against the default gather kernel
+on scattered columns.
     python tools/exp_fused_random.py [rows] [nnz per row] [pattern]"""
 import ctypes as C
 import os
@@ -25,22 +26,16 @@ torch.cuda.synchronize()
 fused = lambda: capi.hellspmv_dot_device["D"](h, p(out), None, p(z), None, 1.0, p(m["cM"]), p(m["rP"]), 32, p(m["hack_offsets"]), p(m["rS"]), n,
                                               p(x), 0.0, 0)
 plain = lambda: capi.hellspmv["D"](h, p(z), None, 1.0, p(m["cM"]), p(m["rP"]), 32, p(m["hack_offsets"]), p(m["rS"]), None, L, n, p(x), 0.0, 0)
-sweep_fn = capi.lib.spgpuDhellspmvSweepExperiment
-sweep_fn.restype = None
-sweep_fn.argtypes = [capi.Handle, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
-
-
-def sweep(packs, blocks):
-    return lambda: sweep_fn(h, p(z), p(m["cM"]), p(m["rP"]), 32, p(m["hack_offsets"]), p(m["rS"]), n, p(x), packs, blocks)
+def sweep():
+    capi.spgpuSetSpmvForm(h, capi.FORM_SWEEP)
+    plain()
+    capi.spgpuSetSpmvForm(h, capi.FORM_AUTO)
 
 
 plain()
 torch.cuda.synchronize()
 want = z.clone()
-cases = [("fused spmv+dot", fused), ("spmv alone", plain)]
-for packs in (2, 4, 8, 16):
-    for blocks in (512, 1024, 2048, 4096):
-        cases.append((f"sweep {2 * packs:2d} rows/lane, {blocks} workgroups", sweep(packs, blocks)))
+cases = [("fused spmv+dot", fused), ("spmv alone", plain), ("sweep form (32 rows per lane)", sweep)]
 for name, fn in cases:
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(s):
