@@ -37,13 +37,15 @@ one, zero = capi.scalar(letter, 1.0), capi.scalar(letter, 0.0)
 x = synth.device_vector(n, letter, 3)
 z = torch.zeros(n, dtype=x.dtype, device="cuda:0")
 xs = x.cpu().numpy()
-FORMS = {"auto": 0, "gather": 1, "strips": 2, "tile0": 3, "tile1": 3, "tile2": 3, "tile3": 3}
+FORMS = {"auto": 0, "gather": 1, "strips": 2, "tile0": 3, "tile1": 3, "tile2": 3, "tile3": 3, "sweep": 4}
 DEEP_CAP = int(os.environ.get("SPGPU_DEEP_CAP", "256"))
 
 
 def shape_of(form, ordered):
     """spmv_tail parameters of the kernel that runs (tests/oracle_api.py slab_shape); a row order switches the deep split on"""
     deep = DEEP_CAP if (ordered and os.environ.get("SPGPU_DEEP_SPLIT", "-1") != "0") or os.environ.get("SPGPU_DEEP_SPLIT") == "1" else 0
+    if form == "sweep":
+        return dict(group_rows=64, rows_per_lane=1, step=1, tail_lanes=0, phases=1)      # ascending k, nothing else
     if form.startswith("ragged"):
         return O.slab_shape(letter, "ragged", 0, deep_cap=deep)
     if form.startswith("tile"):
