@@ -53,7 +53,8 @@ void spgpuTuningReload(void);
  *           5.85).  A row's products are added in ascending k -- the reference's one-thread-per-row order
  *           (hell_spmv_base_template.cuh:104-215) -- which is NOT the bit pattern of the other forms for fp32, for complex
  *           fp64 and on rows short enough to engage the whole-wave tail; without rIdx only (with rIdx: as AUTO).  On
- *           matrices with locality between neighbouring rows this form is several times SLOWER than the others.
+ *           matrices with locality between neighbouring rows, or with rows of very unequal length (a lane walks its 32
+ *           rows to the longest of them), this form is several times SLOWER than the others.
  *
  * The hint applies to every later SpMV call on the handle, from any thread; SPGPU_X_STRIPS / SPGPU_X_TILE in the
  * environment override it.
