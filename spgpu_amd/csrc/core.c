@@ -245,6 +245,7 @@ void spgpuTuningReload(void)
     t.deepCap = envInt("SPGPU_DEEP_CAP", 256);
     t.ragged = envInt("SPGPU_RAGGED", 1);
     t.raggedShape = envInt("SPGPU_RAGGED_SHAPE", 0);
+    t.pipeGroups = envInt("SPGPU_PIPE_GROUPS", 0);
     t.l1Nt = envInt("SPGPU_L1_NT", -1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);

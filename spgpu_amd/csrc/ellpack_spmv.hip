@@ -81,6 +81,7 @@ template <typename T> struct SlabArgs {
     T* deepPartials;             /* [SPGPU_DEEP_ENTRIES][32] row sums over the columns < deepCap */
     T* deepItemSums;             /* [SPGPU_DEEP_ITEMS][32] */
     int xcdRun;                  /* raggedSpmvKernel: row blocks per XCD run (0: hardware order) */
+    int pipeRanges;              /* pipeSpmvKernel: ranges per workgroup */
 };
 
 constexpr int kBlockThreads = 256;
@@ -943,6 +944,8 @@ __global__ __launch_bounds__(kBlockThreads) void sweepSpmvKernel(const SlabArgs<
 __device__ unsigned long long* spgpuTraceBuffer;
 #endif
 #include "ragged_spmv.hip.h"
+#include "share_spmv.hip.h"
+#include "pipe_spmv.hip.h"
 
 /* ---- host side ----------------------------------------------------------- */
 
@@ -1134,6 +1137,22 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     /* ELL says how long its longest row is: when none can exceed the cap nothing registers and the two launches behind
      * the main kernel (~5 us each when empty) are left out; HELL does not say */
     const bool deepPossible = IS_HELL || a.maxNnz > a.deepCap;
+    if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && tune->ragged == 3) {
+        /* rows ordered by length: one resident workgroup per CU, the next block prepared beside the stream (pipe_spmv.hip.h) */
+        a.wideIO = 0;
+        a.feedback = nullptr;
+        spgpuNoteSpmvForm(handle, form != SPGPU_SPMV_FORM_GATHER ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
+        launchPipe<T, WIDE, IS_HELL>(stream, a, tune->pipeGroups > 0 ? tune->pipeGroups : handle->multiProcessorCount, form != SPGPU_SPMV_FORM_GATHER);
+        return;
+    }
+    if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && tune->ragged == 2) {
+        /* rows ordered by length: shares of equal work, one launch, no state (share_spmv.hip.h) */
+        a.wideIO = 0;
+        a.feedback = nullptr;
+        spgpuNoteSpmvForm(handle, form != SPGPU_SPMV_FORM_GATHER ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
+        launchShare<T, WIDE, IS_HELL>(stream, a, tune->raggedShape, form != SPGPU_SPMV_FORM_GATHER);
+        return;
+    }
     if (deepSplit && tune->ragged != 0) {
         /* the queue-driven kernel for rows ordered by length (ragged_spmv.hip.h); x through an LDS tile unless the
          * caller asked for plain gathers */

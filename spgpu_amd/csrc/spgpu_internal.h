@@ -96,6 +96,7 @@ typedef struct SpgpuTuning {
     int deepCap;     /* 256 */
     int ragged;      /* 1: the queue-driven kernel where the deep split is on */
     int raggedShape; /* 0 */
+    int pipeGroups;  /* 0: one workgroup per CU (tests: fewer, so that small matrices run several blocks per workgroup) */
     int l1Nt;        /* -1: by size */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);

@@ -423,6 +423,7 @@ for _L, _T in SCALAR.items():
                    i32, i32, i32]
 
 DEEP_CAP = 256   # SPGPU_DEEP_CAP default
+SHARE_CHUNK = 48  # columns per item of shareSpmvKernel (every type)
 # deepItemsKernel (csrc/ellpack_spmv.hip launchDeep): phases = 64 / (32 / rows per lane); items of 64 columns
 DEEP_SHAPE = {"S": dict(deep_phases=8, deep_chunk=64), "D": dict(deep_phases=4, deep_chunk=64),
               "C": dict(deep_phases=4, deep_chunk=64), "Z": dict(deep_phases=2, deep_chunk=64)}
@@ -451,6 +452,10 @@ def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0):
     launchSlabFamily / launchTiled.  None for the shapes without a tail (complex fp64 outside the deep split: 2 phases)."""
     rpl = {"S": 4, "D": 2, "C": 2, "Z": 1}[letter]
     deep = dict(deep_cap=deep_cap, **DEEP_SHAPE[letter]) if deep_cap > 0 else {}
+    if form == "share":    # shareSpmvKernel (csrc/share_spmv.hip.h): (sub-group, chunk) items, 48 columns per chunk, the
+        phases = 2 * rpl   # chunk sums of a sub-group added in chunk order
+        return dict(group_rows=32, rows_per_lane=rpl, step=phases * (2 if rpl >= 4 else 3), tail_lanes=0, phases=phases,
+                    deep_cap=SHARE_CHUNK, deep_phases=phases, deep_chunk=SHARE_CHUNK)
     if form == "ragged":   # raggedSpmvKernel: one wavefront per 32-row sub-group, 64 / (32 / rpl) phases, no tail rows
         phases = 2 * rpl
         return dict(group_rows=32, rows_per_lane=rpl, step=phases * (2 if rpl >= 4 else 3), tail_lanes=0, phases=phases, **deep)

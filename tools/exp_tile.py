@@ -46,6 +46,8 @@ def shape_of(form, ordered):
     deep = DEEP_CAP if (ordered and os.environ.get("SPGPU_DEEP_SPLIT", "-1") != "0") or os.environ.get("SPGPU_DEEP_SPLIT") == "1" else 0
     if form == "sweep":
         return dict(group_rows=64, rows_per_lane=1, step=1, tail_lanes=0, phases=1)      # ascending k, nothing else
+    if form.startswith(("share", "pipe")):
+        return O.slab_shape(letter, "share")
     if form.startswith("ragged"):
         return O.slab_shape(letter, "ragged", 0, deep_cap=deep)
     if form.startswith("tile"):
@@ -74,16 +76,19 @@ def run(h, label, forms):
     rows = h["rows"]
     hacks = (rows + 31) // 32
     alg = h["nnz"] * (elem + 4) + rows * (4 + elem) + n * elem + hacks * 4 + (rows * 4 if h.get("rIdx") is not None else 0)
+    r_idx = h.get("rIdx")
+    if os.environ.get("EXP_IDENTITY_RIDX") and r_idx is not None:      # timing only: same kernel, z written in row order
+        r_idx = torch.arange(rows, dtype=torch.int32, device="cuda")
     call = lambda: capi.hellspmv[letter](handle, p(z), None, one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
-                                         None if os.environ.get("EXP_DROP_RIDX") else p(h.get("rIdx")), 32, rows, p(x), zero, 0)
+                                         None if os.environ.get("EXP_DROP_RIDX") else p(r_idx), 32, rows, p(x), zero, 0)
     for full in forms:
         form, _, xcd = full.partition("x")          # "ragged0x4": shape 0 with runs of 4 row blocks per XCD
         os.environ["SPGPU_XCD_ORDER"] = xcd or os.environ.get("EXP_XCD_ORDER", "0")
         os.environ["SPGPU_X_TILE_SHAPE"] = form[4:] if form.startswith("tile") else "0"
-        os.environ["SPGPU_RAGGED"] = "1" if form.startswith("ragged") else "0"      # raggedN: shape N with the tile; raggedg: gathers
-        os.environ["SPGPU_RAGGED_SHAPE"] = form[6:] if form.startswith("ragged") and form[6:].isdigit() else "0"
+        os.environ["SPGPU_RAGGED"] = "3" if form.startswith("pipe") else "2" if form.startswith("share") else "1" if form.startswith("ragged") else "0"      # raggedN / shareN: shape N with the tile; raggedg / shareg: gathers
+        os.environ["SPGPU_RAGGED_SHAPE"] = form[6:] if form.startswith("ragged") and form[6:].isdigit() else form[5:] if form.startswith("share") and form[5:].isdigit() else "0"
         capi.spgpuTuningReload()
-        capi.spgpuSetSpmvForm(handle, 1 if form == "raggedg" else 0 if form.startswith("ragged") else 3 if form.startswith("tile") else FORMS[form])
+        capi.spgpuSetSpmvForm(handle, 1 if form in ("raggedg", "shareg", "pipeg") else 0 if form.startswith(("ragged", "share", "pipe")) else 3 if form.startswith("tile") else FORMS[form])
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(stream):
             for _ in range(3):
@@ -119,11 +124,12 @@ if "mild" in cases:
     # the ordered power-law case without its long rows
     rng = np.random.default_rng(1)
     lengths = rng.integers(24, 41, size=n).astype(np.int32)
-    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, "near", 2048, letter, seed=5)
+    mild_pattern = os.environ.get("EXP_MILD_PATTERN", "near")
+    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, mild_pattern, 2048, letter, seed=5)
     torch.cuda.synchronize()
-    for name, order in [("plain", None)] + [(f"sorted window {w}", (w, 0)) for w in (1024, 2048, 4096)]:
+    for name, order in ([] if os.environ.get("EXP_ONLY_WINDOWED") else [("plain", None)]) + [(f"sorted window {w}", (w, 0)) for w in (int(v) for v in os.environ.get("EXP_MILD_WINDOWS", "1024,2048,4096").split(","))]:
         h = formats.coo_to_ordered_hell_device(handle, n, rows_t, cols_t, vals_t, letter, 32, *(order or (0, 0)), order=order is not None)
-        run(h, f"24..40/row near, {name}", os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(","))
+        run(h, f"24..40/row {mild_pattern}, {name}", os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(","))
         del h
         torch.cuda.empty_cache()
     del rows_t, cols_t, vals_t

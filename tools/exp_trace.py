@@ -21,7 +21,7 @@ if case == "powerlaw":
     lengths = synth.power_law_lengths(n, mean=32.0, max_len=2048, seed=5)
 else:
     lengths = np.random.default_rng(1).integers(24, 41, size=n).astype(np.int32)
-coo = synth.ragged_coo_on_device(lengths, n, "near", 2048, "D", seed=5)
+coo = synth.ragged_coo_on_device(lengths, n, os.environ.get("EXP_PATTERN", "near"), 2048, "D", seed=5)
 h = formats.coo_to_ordered_hell_device(handle, n, *coo, "D", 32, window, long_rows)
 x = synth.device_vector(n, "D", 3)
 z = torch.zeros(n, dtype=torch.float64, device="cuda")

@@ -1,6 +1,9 @@
 #!/bin/bash
-# Scratch wrapper for one-off runs on the GPU box:  gpurun -- 'bash tools/run_exp.sh'
-# (edit the commands below; everything that is kept lives in tools/*.py and profiles/)
 cd /root/repo
-export EXP_PATTERNS=band,near EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256 EXP_FORMS=ragged0
-timeout -k 10 300 python tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep "^D "
+mkdir -p gpurun_out
+SPGPU_LIB=/root/repo/spgpu_amd/lib_ab/libspgpu.so timeout -k 10 120 python tools/dbg_pipe.py 3 2>&1 | grep -v amdgpu.ids | grep "^form" | tee gpurun_out/r3_dbg.log
+timeout -k 10 600 python -m pytest tests/test_gpu_share.py -q -m gpu -k "pipe or kernel1 or kernel2" > gpurun_out/r3_pipe_tests.log 2>&1
+rc=$?
+tail -5 gpurun_out/r3_pipe_tests.log
+[ $rc -eq 124 ] && exit 1
+for i in 1 2 3; do timeout -k 10 600 python -m pytest tests/test_gpu_share.py -q -m gpu -k "kernel2" 2>&1 | tail -1; done
