@@ -80,7 +80,13 @@ void spgpuDestroy(spgpuHandle_t pHandle);
 void spgpuStreamCreate(spgpuHandle_t pHandle, hipStream_t* stream);
 void spgpuStreamDestroy(hipStream_t stream);
 
-/* reference: core.h:124 / core.c:64-74.  stream == 0 restores defaultStream. */
+/* reference: core.h:124 / core.c:64-74.  stream == 0 restores defaultStream.
+ * Calls of one handle queued on DIFFERENT streams may be in flight together, as with the reference (its kernels share
+ * nothing through the handle): the scratch the ELL/HELL SpMV uses for matrices with a row order (rIdx) exists once per
+ * stream -- the first time a handle is given a stream, this call allocates ~16 MiB of device memory for it (a blocking
+ * allocation: call it outside stream captures; up to 8 streams per handle, later ones run a kernel that needs none).
+ * Calls queued on ONE stream run in order.  The reductions (dot, nrm2, asum, amax) synchronise their stream and use
+ * one scratch per handle: one reduction of a handle at a time, as the reference's one handle per host thread. */
 void spgpuSetStream(spgpuHandle_t pHandle, hipStream_t stream);
 
 /* reference: core.h:131 / core.c:76-80. */

@@ -13,6 +13,36 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* ---- deep lists of the ELL/HELL SpMV (spgpu_internal.h): one per stream ---- */
+#define DEEP_HEAD_BYTES (SPGPU_DEEP_HEAD_INTS * sizeof(int))
+#define DEEP_ENTRY_BYTES ((size_t)SPGPU_DEEP_ENTRIES * sizeof(SpgpuDeepEntry))
+#define DEEP_ITEM_ENTRY_BYTES ((size_t)SPGPU_DEEP_ITEMS * sizeof(int))
+#define DEEP_PARTIAL_BYTES ((size_t)SPGPU_DEEP_ENTRIES * 32 * 16)
+#define DEEP_ITEM_SUM_BYTES ((size_t)SPGPU_DEEP_ITEMS * 32 * 16)
+
+/* Gives `stream` a list if it has none and the table has room (device already current).  Allocates and clears with a
+ * blocking call: this runs in spgpuCreate / spgpuSetStream, outside any launch path and outside any stream capture. */
+static void deepListFor(SpgpuPrivateHandle* h, hipStream_t stream)
+{
+    pthread_mutex_lock(&h->formLock);
+    int known = 0;
+    for (int i = 0; i < h->deepStreams; ++i)
+        known |= h->deepStream[i] == stream;
+    if (!known && h->deepStreams < SPGPU_DEEP_STREAMS) {
+        void* p = NULL;
+        if (hipMalloc(&p, DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES + DEEP_PARTIAL_BYTES + DEEP_ITEM_SUM_BYTES) == hipSuccess) {
+            if (hipMemset(p, 0, DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES) == hipSuccess) {
+                h->deepScratch[h->deepStreams] = p;
+                h->deepStream[h->deepStreams] = stream;
+                h->deepStreams += 1;
+            } else {
+                hipFree(p);
+            }
+        }
+    }
+    pthread_mutex_unlock(&h->formLock);
+}
+
 spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
 {
     if (!pHandle)
@@ -68,6 +98,9 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     h->magic = SPGPU_HANDLE_MAGIC;
     pthread_mutex_init(&h->formLock, NULL);
     h->spmvForm = SPGPU_SPMV_FORM_AUTO;
+    hipSetDevice(device);
+    deepListFor(h, h->pub.defaultStream); /* failing that, ordered matrices run the kernel that needs no list */
+    hipSetDevice(previous);
 
     *pHandle = &h->pub;
     return SPGPU_SUCCESS;
@@ -86,8 +119,8 @@ void spgpuDestroy(spgpuHandle_t pHandle)
      * for defaultStream, before freeing them.  A graph captured from this handle must not be replayed after this. */
     hipDeviceSynchronize();
     hipFree(h->reduceScratch);
-    if (h->deepScratch)
-        hipFree(h->deepScratch);
+    for (int i = 0; i < h->deepStreams; ++i)
+        hipFree(h->deepScratch[i]);
     hipHostFree(h->reduceHost);
     hipHostFree(h->formFeedback);
     hipStreamDestroy(h->pub.defaultStream);
@@ -115,6 +148,21 @@ void spgpuSetStream(spgpuHandle_t pHandle, hipStream_t stream)
 {
     SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
     h->pub.currentStream = stream ? stream : h->pub.defaultStream;
+    /* a stream the handle has not seen before gets a deep list of its own (see spgpu_internal.h): the reference's SpMV has
+     * no state shared between streams (hell_spmv_base_template.cuh:336-345, core.c:64-74), so neither may this one */
+    int known = 0;
+    pthread_mutex_lock(&h->formLock);
+    for (int i = 0; i < h->deepStreams; ++i)
+        known |= h->deepStream[i] == h->pub.currentStream;
+    const int room = h->deepStreams < SPGPU_DEEP_STREAMS;
+    pthread_mutex_unlock(&h->formLock);
+    if (!known && room) {
+        int previous = 0;
+        hipGetDevice(&previous);
+        hipSetDevice(h->pub.device);
+        deepListFor(h, h->pub.currentStream);
+        hipSetDevice(previous);
+    }
 }
 
 hipStream_t spgpuGetStream(spgpuHandle_t pHandle)
@@ -157,39 +205,22 @@ int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows)
     return slot;
 }
 
-/* ---- deep list of the ELL/HELL SpMV (spgpu_internal.h) ---- */
 spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, SpgpuDeepList* list)
 {
     SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
-    const size_t headBytes = SPGPU_DEEP_HEAD_INTS * sizeof(int);
-    const size_t entryBytes = (size_t)SPGPU_DEEP_ENTRIES * sizeof(SpgpuDeepEntry);
-    const size_t itemEntryBytes = (size_t)SPGPU_DEEP_ITEMS * sizeof(int);
-    const size_t partialBytes = (size_t)SPGPU_DEEP_ENTRIES * 32 * 16;
-    const size_t itemSumBytes = (size_t)SPGPU_DEEP_ITEMS * 32 * 16;
+    char* base = NULL;
     pthread_mutex_lock(&h->formLock);
-    if (!h->deepScratch) {
-        /* first use: one allocation and one blocking memset (not capturable in a graph: warm the handle up first) */
-        int previous = 0;
-        hipGetDevice(&previous);
-        hipSetDevice(h->pub.device);
-        void* p = NULL;
-        if (hipMalloc(&p, headBytes + entryBytes + itemEntryBytes + partialBytes + itemSumBytes) == hipSuccess) {
-            if (hipMemset(p, 0, headBytes + entryBytes + itemEntryBytes) == hipSuccess)
-                h->deepScratch = p;
-            else
-                hipFree(p);
-        }
-        hipSetDevice(previous);
-    }
-    char* base = (char*)h->deepScratch;
+    for (int i = 0; i < h->deepStreams; ++i)
+        if (h->deepStream[i] == h->pub.currentStream)
+            base = (char*)h->deepScratch[i];
     pthread_mutex_unlock(&h->formLock);
     if (!base)
-        return SPGPU_OUTOFMEMORY;
+        return SPGPU_UNSUPPORTED;
     list->header = (int*)base;
-    list->entries = (SpgpuDeepEntry*)(base + headBytes);
-    list->itemEntry = (int*)(base + headBytes + entryBytes);
-    list->partials = base + headBytes + entryBytes + itemEntryBytes;
-    list->itemSums = base + headBytes + entryBytes + itemEntryBytes + partialBytes;
+    list->entries = (SpgpuDeepEntry*)(base + DEEP_HEAD_BYTES);
+    list->itemEntry = (int*)(base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES);
+    list->partials = base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES;
+    list->itemSums = base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES + DEEP_PARTIAL_BYTES;
     return SPGPU_SUCCESS;
 }
 

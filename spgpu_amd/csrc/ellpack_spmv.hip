@@ -1122,6 +1122,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     a.deepItemEntry = nullptr;
     a.deepPartials = nullptr;
     a.deepItemSums = nullptr;
+    bool noDeepList = false;
     if (deepSplit) {
         SpgpuDeepList list;
         if (spgpuDeepScratch(handle, &list) == SPGPU_SUCCESS) {
@@ -1132,27 +1133,29 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             a.deepItemSums = static_cast<T*>(list.itemSums);
         } else {
             deepSplit = false;
+            noDeepList = true;
         }
     }
-    /* ELL says how long its longest row is: when none can exceed the cap nothing registers and the two launches behind
-     * the main kernel (~5 us each when empty) are left out; HELL does not say */
-    const bool deepPossible = IS_HELL || a.maxNnz > a.deepCap;
     if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && tune->ragged == 3) {
         /* rows ordered by length: one resident workgroup per CU, the next block prepared beside the stream (pipe_spmv.hip.h) */
         a.wideIO = 0;
         a.feedback = nullptr;
         spgpuNoteSpmvForm(handle, form != SPGPU_SPMV_FORM_GATHER ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
-        launchPipe<T, WIDE, IS_HELL>(stream, a, tune->pipeGroups > 0 ? tune->pipeGroups : handle->multiProcessorCount, form != SPGPU_SPMV_FORM_GATHER);
+        launchPipe<T, WIDE, IS_HELL>(stream, a, tune->pipeGroups > 0 ? tune->pipeGroups : handle->multiProcessorCount, form != SPGPU_SPMV_FORM_GATHER, tune->raggedShape);
         return;
     }
-    if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && tune->ragged == 2) {
-        /* rows ordered by length: shares of equal work, one launch, no state (share_spmv.hip.h) */
+    if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && (tune->ragged == 2 || (noDeepList && tune->ragged != 0))) {
+        /* rows ordered by length: shares of equal work, one launch, no state (share_spmv.hip.h) -- asked for, or this
+         * stream of the handle has no deep list (more than SPGPU_DEEP_STREAMS streams, or its allocation failed) */
         a.wideIO = 0;
         a.feedback = nullptr;
         spgpuNoteSpmvForm(handle, form != SPGPU_SPMV_FORM_GATHER ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
         launchShare<T, WIDE, IS_HELL>(stream, a, tune->raggedShape, form != SPGPU_SPMV_FORM_GATHER);
         return;
     }
+    /* ELL says how long its longest row is: when none can exceed the cap nothing registers and the two launches behind
+     * the main kernel (~5 us each when empty) are left out; HELL does not say */
+    const bool deepPossible = IS_HELL || a.maxNnz > a.deepCap;
     if (deepSplit && tune->ragged != 0) {
         /* the queue-driven kernel for rows ordered by length (ragged_spmv.hip.h); x through an LDS tile unless the
          * caller asked for plain gathers */

@@ -34,7 +34,7 @@
 constexpr int kPipeRanges = 32; /* ranges a workgroup can own */
 constexpr int kSpinLimit = 1 << 23; /* polls of an LDS word (~0.1 us each) before a wavefront gives up: a second */
 
-template <typename T, int RPL, bool IS_HELL, bool BY_WORK, int UNROLL, int WAVES, int TILE_BYTES, bool XTILE, int CHUNK_STAGES>
+template <typename T, int RPL, bool IS_HELL, bool BY_WORK, int UNROLL, int WAVES, int TILE_BYTES, bool XTILE, int CHUNK_STAGES, int AHEAD>
 __global__ __launch_bounds__(WAVES * kWave) void pipeSpmvKernel(const SlabArgs<T> a)
 {
     constexpr int LPC = 32 / RPL;   /* lanes per slab column of a sub-group */
@@ -427,7 +427,8 @@ __global__ __launch_bounds__(WAVES * kWave) void pipeSpmvKernel(const SlabArgs<T
         int blk;   /* the block the stage belongs to */
         bool last; /* last stage of its item */
     };
-    constexpr int AHEAD = 2;
+    /* AHEAD stages are in flight per wavefront while one is consumed (template parameter: the fewer wavefronts a workgroup
+     * has, the more registers each may spend on stages in flight) */
 
     /* ---- fetch cursor --------------------------------------------------------------------------------------------- */
     int cBlk = -1, cItems = 0, cUsed = 0, cChunksDone = 0; /* the block the cursor is in */
@@ -699,14 +700,16 @@ __global__ __launch_bounds__(WAVES * kWave) void pipeSpmvKernel(const SlabArgs<T
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i)
             fetchNext(ring[i]);
-        static_assert(AHEAD == 2, "the rotation below is written out for a ring of three");
-        for (;;) { /* the ring rotates by name, not by copying registers */
-            if (ring[0].row < 0) break;
-            step(ring[0], ring[2]);
-            if (ring[1].row < 0) break;
-            step(ring[1], ring[0]);
-            if (ring[2].row < 0) break;
-            step(ring[2], ring[1]);
+        for (bool more = true; more;) { /* the ring rotates by name (the loop below is unrolled), not by copying registers */
+#pragma unroll
+            for (int i = 0; i <= AHEAD; ++i) {
+                if (more) {
+                    if (ring[i].row < 0)
+                        more = false;
+                    else
+                        step(ring[i], ring[(i + AHEAD) % (AHEAD + 1)]);
+                }
+            }
         }
         /* the ring is empty: every block up to the cursor's has been consumed as far as this wavefront is concerned */
         leaveUpTo(cBlk);
@@ -723,13 +726,13 @@ __global__ __launch_bounds__(WAVES * kWave) void pipeSpmvKernel(const SlabArgs<T
 #ifndef SPGPU_PIPE_UNROLL
 #define SPGPU_PIPE_UNROLL(RPL) ((RPL) >= 4 ? 2 : 3)
 #endif
-/* One workgroup per CU: the grid is the number of CUs (fewer for small matrices: a workgroup should own some blocks). */
-template <typename T, int RPL, bool IS_HELL>
-static void launchPipe(hipStream_t stream, const SlabArgs<T>& a, int computeUnits, bool tiled)
+/* One workgroup per CU: the grid is the number of CUs (fewer for small matrices: a workgroup should own some blocks).
+ * Shapes (SPGPU_RAGGED_SHAPE; 0 is the default): wavefronts per workgroup / stages in flight per wavefront. */
+template <typename T, int RPL, bool IS_HELL, int WAVES, int AHEAD>
+static void launchPipeShape(hipStream_t stream, const SlabArgs<T>& a, int computeUnits, bool tiled)
 {
     constexpr int UNROLL = SPGPU_PIPE_UNROLL(RPL);
     constexpr int STAGES = 48 / ((kWave / (32 / RPL)) * UNROLL) > 0 ? 48 / ((kWave / (32 / RPL)) * UNROLL) : 1; /* chunks of 48 columns */
-    constexpr int WAVES = 16;
     const long long subs = ((long long)a.rows + 31) / 32;
     const bool byWork = IS_HELL && a.hackSize % 32 == 0;
     long long groups = (subs + 31) / 32; /* at least 1 024 rows each */
@@ -745,15 +748,29 @@ static void launchPipe(hipStream_t stream, const SlabArgs<T>& a, int computeUnit
     do {                                                                                                              \
         if constexpr (IS_HELL) {                                                                                      \
             if (byWork) {                                                                                             \
-                hipLaunchKernelGGL((pipeSpmvKernel<T, RPL, true, true, UNROLL, WAVES, BYTES, XT, STAGES>), grid, block, 0, stream, b); \
+                hipLaunchKernelGGL((pipeSpmvKernel<T, RPL, true, true, UNROLL, WAVES, BYTES, XT, STAGES, AHEAD>), grid, block, 0, stream, b); \
                 break;                                                                                                \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((pipeSpmvKernel<T, RPL, IS_HELL, false, UNROLL, WAVES, BYTES, XT, STAGES>), grid, block, 0, stream, b); \
+        hipLaunchKernelGGL((pipeSpmvKernel<T, RPL, IS_HELL, false, UNROLL, WAVES, BYTES, XT, STAGES, AHEAD>), grid, block, 0, stream, b); \
     } while (0)
     if (tiled)
         SPGPU_PIPE(49152, true);
     else
         SPGPU_PIPE(16384, false);
 #undef SPGPU_PIPE
+}
+
+template <typename T, int RPL, bool IS_HELL>
+static void launchPipe(hipStream_t stream, const SlabArgs<T>& a, int computeUnits, bool tiled, int shape)
+{
+    switch (shape) {
+#ifdef SPGPU_TUNING_VARIANTS
+    case 1: launchPipeShape<T, RPL, IS_HELL, 12, 3>(stream, a, computeUnits, tiled); break;
+    case 2: launchPipeShape<T, RPL, IS_HELL, 12, 4>(stream, a, computeUnits, tiled); break;
+    case 3: launchPipeShape<T, RPL, IS_HELL, 8, 6>(stream, a, computeUnits, tiled); break;
+    case 4: launchPipeShape<T, RPL, IS_HELL, 8, 8>(stream, a, computeUnits, tiled); break;
+#endif
+    default: launchPipeShape<T, RPL, IS_HELL, 16, 2>(stream, a, computeUnits, tiled); break;
+    }
 }

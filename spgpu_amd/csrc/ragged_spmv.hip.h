@@ -38,6 +38,8 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
 
     __shared__ __attribute__((aligned(16))) T tile[TILE_ELEMS];
     __shared__ int lens[ROWS];        /* row lengths as walked here (deep sub-groups: cut at deepCap) */
+    __shared__ int dests[ROWS];       /* rIdx of the workgroup's rows: fetched from global memory at the end of a sub-group it would be
+                                         waited for with vmcnt(0) -- counters retire in order -- and drain the wavefront's prefetch */
     __shared__ int bases[ROWS / RPL]; /* first slot of every RPL-row strip, in elements */
     __shared__ int depths[SUBS];      /* longest walked row of every sub-group */
     __shared__ int deepSlots[SUBS];   /* its entry in the deep list, or -1 */
@@ -65,13 +67,14 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
      * loads, together with the first stages of the stream.  Measured with 4 round trips and 4 barriers: 12.7 us, a
      * third of a workgroup's life (profiles/r02b_ragged_workgroup_trace.txt). ------------------------------------- */
     constexpr int RPT = (ROWS + BLOCK - 1) / BLOCK; /* rows a thread looks at; 32 consecutive rows = 32 consecutive lanes */
-    int myLen[RPT], myBase[RPT];
+    int myLen[RPT], myBase[RPT], myDest[RPT];
 #pragma unroll
     for (int j = 0; j < RPT; ++j) { /* round trip 1 */
         const int i = threadIdx.x + j * BLOCK;
         const long long r = blockRow0 + i;
         const bool live = i < ROWS && r < a.rows;
         myLen[j] = live ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+        myDest[j] = live && a.rIdx ? a.rIdx[r] : (int)r;
         myBase[j] = 0;
         if (live) {
             if constexpr (IS_HELL) {
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
         }
         if (i < ROWS) {
             lens[i] = (slot >= 0 && myLen[j] > a.deepCap) ? a.deepCap : myLen[j];
+            dests[i] = myDest[j];
             if (i % RPL == 0)
                 bases[i / RPL] = myBase[j];
             if ((lane & 31) == 0) {
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
                         if (DEEP && deepSlot >= 0) {
                             a.deepPartials[(size_t)deepSlot * 32 + (size_t)(sub * RPL + t)] = sum[t];
                         } else {
-                            const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+                            const int outRow = dests[s * 32 + sub * RPL + t];
                             a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
                                                   : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
                         }

@@ -56,6 +56,8 @@ __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4
     __shared__ __attribute__((aligned(16))) T buffer[BUFFER_ELEMS]; /* x tile from the front, chunk sums from the back */
     __shared__ T carry[32];                                        /* a sub-group cut by a pass boundary */
     __shared__ int lens[MAXROWS];
+    __shared__ int dests[MAXROWS]; /* rIdx of the pass's rows: fetched from global memory at the end of an item it would be waited for
+                                      with vmcnt(0) -- counters retire in order -- and drain the wavefront's prefetch */
     __shared__ unsigned bases[BY_WORK ? MAXSUBS : MAXROWS / RPL]; /* first slot of a sub-group / of an RPL-row strip */
     __shared__ int depths[MAXSUBS];
     __shared__ int4 subFacts[MAXSUBS]; /* first item, first chunk sum or -1, depth, chunks done earlier */
@@ -127,8 +129,8 @@ __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4
     }
 
     const bool hasBeta = isNotZero(a.beta);
-    auto finishRow = [&](long long r, T sum) {
-        const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+    auto finishRow = [&](int inPass, T sum) { /* row inPass of the pass */
+        const int outRow = dests[inPass];
         a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum, a.beta, a.y[outRow]) : epilogue<false>(a.alpha, sum, a.beta, zeroOf<T>());
     };
 
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4
 
         /* round trip 3: row lengths, slab bases */
         constexpr int RPT = (MAXROWS + BLOCK - 1) / BLOCK; /* rows a lane looks at; 32 consecutive rows = 32 consecutive lanes */
-        int myLen[RPT];
+        int myLen[RPT], myDest[RPT];
         unsigned myBase[RPT];
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4
             const long long r = passRow0 + i;
             const bool live = i < candidates * 32 && r < a.rows;
             myLen[j] = live ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+            myDest[j] = live && a.rIdx ? a.rIdx[r] : (int)r;
             myBase[j] = 0;
             if constexpr (!BY_WORK) {
                 if (live) {
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4
             }
             if (i < MAXROWS) {
                 lens[i] = myLen[j];
+                dests[i] = myDest[j];
                 if constexpr (!BY_WORK) {
                     if (i % RPL == 0)
                         bases[i / RPL] = myBase[j];
@@ -517,9 +521,8 @@ __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4
                         if (park >= 0) {
                             sums[park * 32 + sub * RPL + t] = sum[t];
                         } else {
-                            const long long r = passRow0 + row + sub * RPL + t;
-                            if (r < a.rows)
-                                finishRow(r, sum[t]);
+                            if (passRow0 + row + sub * RPL + t < a.rows)
+                                finishRow(row + sub * RPL + t, sum[t]);
                         }
                     }
                 }
@@ -559,9 +562,8 @@ __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4
                     if (s == 0 && cutShort) {
                         carry[rowInSub] = total;
                     } else {
-                        const long long r = passRow0 + s * 32 + rowInSub;
-                        if (r < a.rows)
-                            finishRow(r, total);
+                        if (passRow0 + s * 32 + rowInSub < a.rows)
+                            finishRow(s * 32 + rowInSub, total);
                     }
                 }
             }
@@ -608,9 +610,9 @@ static void launchShare(hipStream_t stream, const SlabArgs<T>& a, int shape, boo
         return;
     }
     switch (shape) {
-    case 1: SPGPU_SHARE(8, 65536, true, 64); break;
+    case 1: SPGPU_SHARE(8, 57344, true, 64); break;
     case 2: SPGPU_SHARE(8, 49152, true, 32); break;
-    default: SPGPU_SHARE(8, 65536, true, 32); break;
+    default: SPGPU_SHARE(8, 57344, true, 32); break;
     }
 #undef SPGPU_SHARE
 }

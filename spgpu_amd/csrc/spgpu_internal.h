@@ -18,6 +18,7 @@ extern "C" {
 
 /* The public struct is the FIRST member, so a spgpuHandle_t is also a pointer
  * to this record. */
+#define SPGPU_DEEP_STREAMS 8
 typedef struct SpgpuPrivateHandle {
     SpgpuHandleStruct pub;
     unsigned magic;
@@ -32,7 +33,11 @@ typedef struct SpgpuPrivateHandle {
     unsigned formNext;
     pthread_mutex_t formLock; /* guards formKey / formRows / formNext */
     int spmvForm;             /* SPGPU_SPMV_FORM_* set by spgpuSetSpmvForm (atomic) */
-    void* deepScratch;        /* device: the deep list (SpgpuDeepList); NULL until first needed */
+    /* deep lists of the ELL/HELL SpMV, one per stream the handle has been given (spgpuCreate: the default stream;
+     * spgpuSetStream: every new one): two SpMVs of one handle in flight on two streams never share a list */
+    void* deepScratch[SPGPU_DEEP_STREAMS];
+    hipStream_t deepStream[SPGPU_DEEP_STREAMS];
+    int deepStreams;
     int lastSpmvForm;         /* form of the most recent ELL/HELL SpMV launch (diagnostic, atomic) */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8
@@ -47,7 +52,10 @@ static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
  * the first call that needs it.  The main kernel registers every 32-row sub-group deeper than deepCap as one ENTRY and
  * its columns beyond the cap as ITEMS of deepChunk columns; deepItemsKernel gives every item to a wavefront,
  * deepFinishKernel adds an entry's item sums in item order, writes z and -- the workgroup that finishes last -- zeroes the
- * header for the next call.  One SpMV of a handle uses the list at a time (calls on one stream do, in order). */
+ * header for the next call.  A list belongs to ONE stream of the handle (calls on one stream run in order); the handle
+ * keeps a list for each of the first SPGPU_DEEP_STREAMS streams it is given -- allocated in spgpuCreate / spgpuSetStream,
+ * never inside an SpMV call -- and an SpMV on a stream without a list runs the kernel that needs none
+ * (share_spmv.hip.h). */
 typedef struct SpgpuDeepEntry {
     int row0;      /* first row of the 32-row sub-group (a multiple of 32) */
     int depth;     /* its longest row */
@@ -64,7 +72,7 @@ typedef struct SpgpuDeepList {
     void* partials;          /* [SPGPU_DEEP_ENTRIES][32] x 16 bytes: row sums over the columns < deepCap */
     void* itemSums;          /* [SPGPU_DEEP_ITEMS][32] x 16 bytes */
 } SpgpuDeepList;
-/* Device pointers of the list, or SPGPU_OUTOFMEMORY. */
+/* Device pointers of the current stream's list, or SPGPU_UNSUPPORTED when that stream has none. */
 spgpuStatus_t spgpuDeepScratch(spgpuHandle_t h, SpgpuDeepList* list);
 
 /* With -DSPGPU_DEBUG every launch is followed by a synchronising error check

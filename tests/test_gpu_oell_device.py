@@ -356,7 +356,7 @@ def test_deep_list_in_a_replayed_graph(gpu):
     capi.spgpuSetStream(gpu, C.c_void_p(side.cuda_stream))
     try:
         with torch.cuda.stream(side):
-            call()                               # warm-up outside the capture: the list is allocated on first use
+            call()                               # warm-up outside the capture (the stream's list exists since spgpuSetStream)
         side.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
@@ -413,3 +413,63 @@ def test_two_handles_on_two_threads_with_deep_rows(gpu):
     for t in threads:
         t.join()
     assert not failures, failures
+
+
+def test_two_streams_of_one_handle_with_deep_rows(gpu):
+    """The reference's SpMV shares nothing between the streams of a handle (hell_spmv_base_template.cuh:336-345; the caller
+    switches streams with spgpuSetStream, core.c:64-74): two ordered power-law SpMVs queued on two streams of ONE handle,
+    20 rounds without a synchronisation in between, both bit for bit the single-stream result.  Every stream the handle is
+    given owns a deep list."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    cases = []
+    for seed, n in ((41, 60000), (42, 90000)):
+        h, sub = _deep_case(gpu, n, seed)
+        x = synth.values_for("D", seed, n)
+        want = O.spmv_tail(sub, x, None, 1.0, 0.0, r_idx=h["rIdx"].cpu().numpy(), **O.slab_shape("D", "ragged", deep_cap=O.DEEP_CAP))
+        cases.append((h, n, formats.to_device(x), want, torch.zeros(n, dtype=torch.float64, device="cuda"), torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    try:
+        for rep in range(20):
+            for h, n, dx, want, dz, stream in cases:        # queued back to back: the two calls overlap on the device
+                capi.spgpuSetStream(gpu, C.c_void_p(stream.cuda_stream))
+                capi.hellspmv["D"](gpu, _dp(dz), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]),
+                                   _dp(h["rIdx"]), 14, n, _dp(dx), 0.0, 0)
+            torch.cuda.synchronize()
+            for h, n, dx, want, dz, stream in cases:
+                assert dz.cpu().numpy().tobytes() == want.tobytes(), (n, rep)
+                dz.zero_()
+            torch.cuda.synchronize()
+    finally:
+        capi.spgpuSetStream(gpu, None)
+
+
+def test_more_streams_than_deep_lists(gpu):
+    """A handle keeps a deep list for the first 8 streams it is given; an SpMV on a later stream runs the kernel that needs
+    none (share_spmv.hip.h) -- other order of additions, so compared with the oracle in THAT order -- and stays correct
+    when several of them are in flight."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 30000
+    handle = capi.create_handle(0)
+    h, sub = _deep_case(handle, n, 51)
+    x = synth.values_for("D", 51, n)
+    r_idx = h["rIdx"].cpu().numpy()
+    with_list = O.spmv_tail(sub, x, None, 1.0, 0.0, r_idx=r_idx, **O.slab_shape("D", "ragged", deep_cap=O.DEEP_CAP))
+    without = O.spmv_tail(sub, x, None, 1.0, 0.0, r_idx=r_idx, **O.slab_shape("D", "share"))
+    dx = formats.to_device(x)
+    streams = [torch.cuda.Stream() for _ in range(11)]
+    outs = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    try:
+        for stream, dz in zip(streams, outs):
+            capi.spgpuSetStream(handle, C.c_void_p(stream.cuda_stream))
+            capi.hellspmv["D"](handle, _dp(dz), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]),
+                               _dp(h["rIdx"]), 14, n, _dp(dx), 0.0, 0)
+        torch.cuda.synchronize()
+        for k, dz in enumerate(outs):       # the default stream holds list 0, the first 7 streams given the others
+            want = with_list if k < 7 else without
+            assert dz.cpu().numpy().tobytes() == want.tobytes(), k
+    finally:
+        capi.spgpuSetStream(handle, None)
+        capi.spgpuDestroy(handle)

@@ -86,7 +86,7 @@ def run(h, label, forms):
         os.environ["SPGPU_XCD_ORDER"] = xcd or os.environ.get("EXP_XCD_ORDER", "0")
         os.environ["SPGPU_X_TILE_SHAPE"] = form[4:] if form.startswith("tile") else "0"
         os.environ["SPGPU_RAGGED"] = "3" if form.startswith("pipe") else "2" if form.startswith("share") else "1" if form.startswith("ragged") else "0"      # raggedN / shareN: shape N with the tile; raggedg / shareg: gathers
-        os.environ["SPGPU_RAGGED_SHAPE"] = form[6:] if form.startswith("ragged") and form[6:].isdigit() else form[5:] if form.startswith("share") and form[5:].isdigit() else "0"
+        os.environ["SPGPU_RAGGED_SHAPE"] = form[6:] if form.startswith("ragged") and form[6:].isdigit() else form[5:] if form.startswith("share") and form[5:].isdigit() else form[4:] if form.startswith("pipe") and form[4:].isdigit() else "0"
         capi.spgpuTuningReload()
         capi.spgpuSetSpmvForm(handle, 1 if form in ("raggedg", "shareg", "pipeg") else 0 if form.startswith(("ragged", "share", "pipe")) else 3 if form.startswith("tile") else FORMS[form])
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
