@@ -46,9 +46,10 @@ def parse():
     p.add_argument("--rhs", type=int, default=16)
     p.add_argument("--spmm-pattern", default="banded", choices=["banded", "random", "window"])
     p.add_argument("--force-split", action="store_true", help="spmm: cut by column ownership even on one rank (rehearsal)")
-    p.add_argument("--exchange", default="needed", choices=["needed", "allgather"],
-                   help="spmm on N>1 ranks: move only the X rows the off-block columns name (one all_to_all per step), or "
-                        "all-gather the whole of X; with 'needed' the all-gather step is timed as well and reported beside it")
+    p.add_argument("--exchange", default="allgather", choices=["allgather", "needed"],
+                   help="spmm, N > 1: what `value` reports.  allgather (default): RCCL all-gather of the dense X per step, BASELINE "
+                        "configs[4] word for word.  needed: only the X rows the off-block columns name (all_to_all).  The other "
+                        "one is measured in the same process and reported under `variants`")
     p.add_argument("--driver", default="c", choices=["c", "torch"],
                    help="spmm: who issues a step -- libspgpu.so's sharded driver (RCCL through dlopen), or torch.distributed")
     p.add_argument("--no-split", action="store_true",
@@ -80,6 +81,34 @@ def committed_traffic(rows, nnz_per_row, pattern, rhs=None):
         if (w.get("rows"), w.get("nnz_per_row"), w.get("pattern"), w.get("rhs")) == (rows, nnz_per_row, pattern, rhs):
             best = int(d["hbm_traffic_bytes_per_launch"])
     return best
+
+
+def vendor():
+    """tools/vendor_context.py (rocSPARSE through ctypes), or None: same-node context numbers, never on the path."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import vendor_context
+        return vendor_context
+    except Exception:  # noqa: BLE001 - context only
+        return None
+
+
+FORM_NAMES = {1: "gathers", 2: "strip x loads", 3: "x tile in LDS", 4: "sweep"}
+
+
+def settle(stream, step, calls=3):
+    """AUTO reads what the sample wavefronts of a COMPLETED launch on the same arrays reported (include/spgpu/tuning.h): a
+    matrix that was just built -- possibly at the address of the previous one -- needs a completed call or two before
+    its form is the one that is timed.  (Round 2 timed the window variant in the form of the banded matrix that had
+    lived at that address: +8 %.)"""
+    for _ in range(calls):
+        step()
+        stream.synchronize()
+
+
+def form_ran(handle):
+    from spgpu_amd import capi
+    return FORM_NAMES.get(capi.spgpuGetLastSpmvForm(handle), "?")
 
 
 def time_launches(stream, fn, steps):
@@ -248,6 +277,11 @@ def bench_powerlaw(args, handle, stream, dev, rows):
     for pattern in ("near", "band", "random"):
         coo = synth.ragged_coo_on_device(lengths, rows, pattern, 2048, letter, seed=5, device=dev)
         torch.cuda.synchronize()
+        if vendor() is not None:   # rocSPARSE CSR (adaptive) on the same rows, as they come: context, never on the path
+            try:
+                out[f"{pattern}_vendor_context"] = vendor().coo_context(stream, rows, rows, lengths, coo[1], coo[2], x, torch.empty_like(z))
+            except Exception as error:  # noqa: BLE001
+                out[f"{pattern}_vendor_context"] = repr(error)
         for name, ordered in ((("sorted", True),) if pattern == "band" else (("plain", False), ("sorted", True))):
             t0 = time.perf_counter()
             h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, 2048, 256, order=ordered)
@@ -257,11 +291,13 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
             call = lambda: capi.hellspmv[letter](handle, p(z), None, C.c_double(1.0), p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]),
                                                  p(h["rS"]), p(h["rIdx"]), 32, rows, p(x), C.c_double(0.0), 0)
-            time_launches(stream, call, 3)
+            with torch.cuda.stream(stream):
+                settle(stream, call)
             t = time_launches(stream, call, 20) / 20
             z.zero_()
             torch.cuda.synchronize()
             time_launches(stream, call, 1)
+            ran = form_ran(handle)
             capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
             hacks = (rows + 31) // 32
             alg = h["nnz"] * (elem + 4) + rows * (4 + elem) + rows * elem + hacks * 4 + (rows * 4 if ordered else 0)
@@ -269,7 +305,7 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             out[f"{pattern}_{name}"] = dict(slots_per_nnz=round(h["slots"] / h["nnz"], 3), ms=round(t * 1e3, 4),
                                             gflops=round(2.0 * h["nnz"] / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
                                             frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), algorithmic_bytes=alg,
-                                            hell_GB=round(h["slots"] * (elem + 4) * 1e-9, 2), build_ms=round(build_s * 1e3, 1),
+                                            hell_GB=round(h["slots"] * (elem + 4) * 1e-9, 2), build_ms=round(build_s * 1e3, 1), form=ran,
                                             parity=check_windows(h, x, z, letter, shape))
             del h
             torch.cuda.empty_cache()
@@ -312,7 +348,7 @@ def bench_c1(handle, stream, dev):
     cg = os.path.join(ROOT, "tools", "cg_amd.bin")
     if os.path.exists(cg):
         try:
-            run = subprocess.run([cg, "1024", "60", "1e-30"], capture_output=True, text=True, timeout=120)
+            run = subprocess.run([cg, "1024", "60", "1e-30", "timing"], capture_output=True, text=True, timeout=120)
             for line in run.stdout.splitlines():
                 if line.startswith("graph replay:"):
                     words = line.replace("(", " ").replace(")", " ").replace(";", " ").split()
@@ -380,9 +416,15 @@ def bench_c3(handle, stream, dev, rows, ell_rows):
     from spgpu_amd import formats
     coo = synth.ragged_coo_on_device(lengths, n, "random", 2048, "S", seed=5, device=dev)
     h = formats.coo_to_ordered_hell_device(handle, n, *coo, "S", 32, 2048, 256)
-    del coo
     x, z = synth.device_vector(n, "S", 3, dev), torch.zeros(n, dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
+    if vendor() is not None:
+        try:
+            out["vendor_context"] = vendor().coo_context(stream, n, n, lengths, coo[1], coo[2], x, torch.empty_like(z), letter="S")
+        except Exception as error:  # noqa: BLE001
+            out["vendor_context"] = repr(error)
+    del coo
+    torch.cuda.empty_cache()
     capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
     call = lambda: capi.hellspmv["S"](handle, p(z), None, 1.0, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
                                       p(h["rIdx"]), 32, n, p(x), 0.0, 0)
@@ -476,9 +518,11 @@ def run_spmv(args, rank, world):
 
     torch.cuda.synchronize()
     with torch.cuda.stream(stream):
+        settle(stream, step)
         for _ in range(args.warmup):
             step()
     stream.synchronize()
+    headline_form = form_ran(handle)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -506,7 +550,8 @@ def run_spmv(args, rank, world):
         roofline=dict(bound="hbm", achieved=round(alg / per_launch * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=round(alg / per_launch * 1e-9 / HBM_PEAK_GBS, 4),
                       traffic=committed_traffic(h["rows"], args.nnz_per_row, args.pattern),
-                      kernel="slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, prefetch after gathers, tail, strip x loads>", algorithmic_bytes_per_launch=alg,
+                      kernel=f"slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, prefetch after gathers, tail> in the form "
+                             f"spgpuGetLastSpmvForm reports: {headline_form}", algorithmic_bytes_per_launch=alg,
                       kernel_ms=round(per_launch * 1e3, 5)),
     )
 
@@ -522,8 +567,13 @@ def run_spmv(args, rank, world):
             t = time_launches(stream, s2, 50) / 50
             a2 = hell_algorithmic_bytes(h["nnz"], h["rows"], h["cols"], hacks, beta_nonzero=True)
             extras[f"{args.pattern}_beta0.5"] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(a2 / t * 1e-9, 1),
-                                                      frac=round(a2 / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4))
+                                                      frac=round(a2 / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4), form=form_ran(handle))
             out["cpu_baseline"] = cpu_baseline(h, x, args.cpu_seconds)
+            if vendor() is not None:
+                try:
+                    extras[f"{args.pattern}_vendor_context"] = vendor().uniform_hell_context(stream, h, x, torch.empty_like(y))
+                except Exception as error:  # noqa: BLE001
+                    extras[f"{args.pattern}_vendor_context"] = repr(error)
             for pattern in ("banded", "window", "random"):
                 if pattern == args.pattern:
                     continue
@@ -531,11 +581,18 @@ def run_spmv(args, rank, world):
                 torch.cuda.empty_cache()
                 h = build(pattern)
                 step = s2 = launcher(h, x, y, z, 1.0, 0.0)
+                with torch.cuda.stream(stream):
+                    settle(stream, step)
                 time_launches(stream, step, 5)
                 t = time_launches(stream, step, 50) / 50
                 extras[pattern] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
-                                       frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4),
+                                       frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4), form=form_ran(handle),
                                        parity=spot_check_hell(h, x, y, z, 1.0, 0.0))
+                if vendor() is not None:   # the vendor library on the same matrix, for context (never on the path)
+                    try:
+                        extras[pattern]["vendor_context"] = vendor().uniform_hell_context(stream, h, x, torch.empty_like(y))
+                    except Exception as error:  # noqa: BLE001
+                        extras[pattern]["vendor_context"] = repr(error)
                 if pattern == "random":
                     # the caller's hint for scattered columns that ascend inside a row (include/spgpu/tuning.h, SWEEP):
                     # 32 rows per lane carried through the columns in step; uniform rows: the same bits as the default
@@ -546,7 +603,7 @@ def run_spmv(args, rank, world):
                     torch.cuda.synchronize()
                     time_launches(stream, step, 1)
                     extras["random_form_sweep"] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
-                                                       frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4),
+                                                       frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4), form=form_ran(handle),
                                                        parity=spot_check_hell(h, x, y, z, 1.0, 0.0))
                     capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
             out["variants"] = extras
@@ -587,6 +644,14 @@ def run_spmv(args, rank, world):
                     configs[name] = dict(error=repr(error))
                 torch.cuda.empty_cache()
             out["configs"] = configs
+            pl = configs.get("powerlaw_fp64", {})
+            target = {name: dict(ms=pl[name]["ms"], frac=pl[name]["frac"], slots_per_nnz=pl[name]["slots_per_nnz"], parity=pl[name]["parity"])
+                      for name in ("band_sorted", "near_sorted", "near_plain") if isinstance(pl.get(name), dict)}
+            target["what"] = ("north_star target: spgpuDhellspmv, fp64, 10 M rows, power-law lengths (mean 32, max 2048), rows ordered "
+                              "on the device (windows of 2048, rows > 256 set aside) and run through rIdx; frac = algorithmic bytes / "
+                              "time / 8 TB/s; bar 0.70")
+            out["config"]["north_star_target"] = target
+            out["target"] = target
             if world == 1:
                 # the N = 1 point of the curve `--gpus N` (N > 1) measures: same sharded SpMM step on one rank
                 one = measure_spmm(args, 0, 1, handle, stream, dev, 50, 5)
@@ -595,6 +660,9 @@ def run_spmv(args, rank, world):
                                         kernel_ms=one["roofline"]["kernel_ms"], parity=one["parity"])
         elif "cpu_baseline" not in out:
             out["cpu_baseline"] = None
+        first = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                 "data", "config", "roofline", "target", "cpu_baseline", "parity"]
+        out = {**{key: out[key] for key in first if key in out}, **{key: value for key, value in out.items() if key not in first}}
         print(json.dumps(out), flush=True)
     capi.spgpuDestroy(handle)
 
@@ -646,7 +714,8 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                            p(part["rS"]), None, L, part["rows"], p(X), C.c_double(beta), 0, k, k, k)
 
     new_rows = lambda rows: torch.empty(rows, k, dtype=torch.float64, device=dev)
-    needed_mode = split and args.exchange == "needed"
+    needed_mode = split and args.exchange == "needed"   # what `value` reports
+    both = split                                          # the other exchange is measured beside it
     distributed = world > 1 or (dist.is_available() and dist.is_initialized())
 
     # ---- the driver of a step: the C ABI (include/spgpu/sharded.h: packing kernel, RCCL and both products issued by the
@@ -688,7 +757,7 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
             first_rows = (C.c_longlong * (world + 1))(*[r * rows_local for r in range(world + 1)])
             own_block = capi.hell_block(own, L)
             rest_block = capi.hell_block(rest, L) if rest is not None else None
-            kinds = [("allgather", capi.EXCHANGE_ALLGATHER)] + ([("needed", capi.EXCHANGE_NEEDED)] if needed_mode else [])
+            kinds = [("allgather", capi.EXCHANGE_ALLGATHER)] + ([("needed", capi.EXCHANGE_NEEDED)] if both else [])
             for name, kind in kinds:
                 plan = capi.ShardedPlan()
                 status = capi.spgpuDhellspmmShardedCreate(C.byref(plan), handle, comm, rank, world, first_rows, C.byref(own_block),
@@ -715,6 +784,9 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
         def step_allgather():
             capi.spgpuDhellspmmShardedStep(plans["allgather"], p(z_local), p(y_local), one, p(x_local), zero)
 
+        def step_needed():
+            capi.spgpuDhellspmmShardedStep(plans["needed"], p(z_local), p(y_local), one, p(x_local), zero)
+
         def products_only():
             capi.spgpuDhellspmmShardedProducts(plan_step, p(z_local), p(y_local), one, p(x_local), zero)
 
@@ -723,12 +795,12 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
             capi.spgpuDhellspmmShardedExchangeWait(plans["allgather"])
 
         def needed_only():
-            capi.spgpuDhellspmmShardedExchange(plan_step, p(x_local))
-            capi.spgpuDhellspmmShardedExchangeWait(plan_step)
+            capi.spgpuDhellspmmShardedExchange(plans["needed"], p(x_local))
+            capi.spgpuDhellspmmShardedExchangeWait(plans["needed"])
 
-        rows_received = lambda: int(capi.spgpuDhellspmmShardedRowsReceived(plan_step))
+        rows_received = lambda: int(capi.spgpuDhellspmmShardedRowsReceived(plans["needed"]))
     else:
-        if needed_mode:
+        if both:
             # only the X rows A_rest names travel: its columns are renumbered into that sorted list.  The local part of
             # the set-up runs first and all ranks agree that it worked before any of them enters the set-up collectives
             # (otherwise: everyone falls back to the all-gather).
@@ -743,22 +815,22 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                 flag = torch.tensor([ready], device=dev, dtype=torch.float64)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ready = float(flag.item())
-            needed_mode = ready > 0.5
+            both = ready > 0.5
+            needed_mode = needed_mode and both
         products_stream = stream.cuda_stream
-        if needed_mode:
-            op = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest_compact, local_product, new_rows, needed=needed,
-                                     products_stream=products_stream)
-            op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows,
-                                               products_stream=products_stream)
-        else:
-            op = op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows,
-                                                    products_stream=products_stream)
+        op_allgather = sharded.ShardedSpmm(dist, rank, world, blocks, own, rest, local_product, new_rows, products_stream=products_stream)
+        op_needed = (sharded.ShardedSpmm(dist, rank, world, blocks, own, rest_compact, local_product, new_rows, needed=needed,
+                                         products_stream=products_stream) if both else None)
+        op = op_needed if needed_mode else op_allgather
 
         def step():
             op.step(z_local, y_local, 1.0, x_local, 0.0)
 
         def step_allgather():
             op_allgather.step(z_local, y_local, 1.0, x_local, 0.0)
+
+        def step_needed():
+            op_needed.step(z_local, y_local, 1.0, x_local, 0.0)
 
         def products_only():
             if rest is None:
@@ -776,11 +848,11 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                 w.wait()
 
         def needed_only():
-            w = op.needed.start(x_local, async_op=False)
+            w = op_needed.needed.start(x_local, async_op=False)
             if w is not None:
                 w.wait()
 
-        rows_received = lambda: (sum(op.needed.recv_splits) - op.needed.recv_splits[rank]) if needed_mode else (world - 1) * rows_local
+        rows_received = lambda: (sum(op_needed.needed.recv_splits) - op_needed.needed.recv_splits[rank]) if both else (world - 1) * rows_local
     torch.cuda.synchronize()
 
     with torch.cuda.stream(stream):
@@ -816,21 +888,22 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
 
     t_compute = timed(products_only, 10)
     t_gather = timed(gather_only, 10) if distributed and (split or world > 1) else 0.0
-    t_needed = timed(needed_only, 10) if needed_mode and distributed else 0.0
-    # the all-gather step beside the needed-rows step (same products, whole X moved)
-    t_step_allgather = 0.0
-    if needed_mode and distributed:
-        t_step_allgather = timed(step_allgather, max(3, steps // 10))
+    t_needed = timed(needed_only, 10) if both and distributed else 0.0
+    # the other exchange's step, measured in the same process (same products; what differs is what moves)
+    t_step_other = 0.0
+    if both and distributed:
+        t_step_other = timed(step_allgather if needed_mode else step_needed, max(3, steps // 10))
         if world > 1:
             torch.cuda.synchronize()
-            t = torch.tensor([t_step_allgather], device=dev, dtype=torch.float64)
+            t = torch.tensor([t_step_other], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_step_allgather = float(t.item())
+            t_step_other = float(t.item())
+    t_step_allgather = t_step_other if needed_mode else 0.0
     # the step under test last, for the parity check below
     with torch.cuda.stream(stream):
         step()
     torch.cuda.synchronize()
-    received = rows_received() if needed_mode else None
+    received = rows_received() if both else None
     for plan in plans.values():
         capi.spgpuDhellspmmShardedDestroy(plan)
     if comm is not None:
@@ -860,7 +933,9 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
         else:
             parity = "bit-exact vs oracle on 1024 rows" if got.tobytes() == want.tobytes() else "MISMATCH"
         out = dict(
-            metric="HELL fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), 1 GPU",
+            metric=(f"row-sharded HELL fp64 SpMM GFLOP/s (A x {k} rhs, weak scaling, {world} GPU" + ("s" if world > 1 else "") + ", "
+                    + ("needed X rows by RCCL all_to_all" if needed_mode else "RCCL all-gather(X)") + " per step) + achieved HBM GB/s of the "
+                    "local product (% of roofline)"),
             value=round(flops_total * steps / wall * 1e-9, 2), unit="GFLOP/s", n_gpus=world, steps=steps,
             warmup=warmup, ms_per_step=round(wall / steps * 1e3, 5), higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f64", data="synthetic",
@@ -880,7 +955,7 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
             spmm=dict(compute_only_ms=round(t_compute * 1e3, 4), allgather_only_ms=round(t_gather * 1e3, 4),
                       compute_only_gflops_total=round(flops_total / t_compute * 1e-9, 1),
                       allgather_GBps_per_rank=round((world - 1) * rows_local * k * 8 / t_gather * 1e-9, 1) if t_gather else None,
-                      needed_rows_only_ms=round(t_needed * 1e3, 4) if needed_mode else None,
+                      needed_rows_only_ms=round(t_needed * 1e3, 4) if both and t_needed else None,
                       needed_rows_received_per_rank=received, driver=driver,
                       allgather_step_ms=round(t_step_allgather * 1e3, 4) if t_step_allgather else None,
                       allgather_step_gflops_total=round(flops_total / t_step_allgather * 1e-9, 1) if t_step_allgather else None),
@@ -899,6 +974,13 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                                              bytes_received_per_rank=(world - 1) * rows_local * k * 8,
                                              note="same products, whole X all-gathered per step; `value` above moves only the X rows "
                                                   "the off-block columns name (DESIGN.md section 6)")
+        if t_step_other and not needed_mode:
+            # the better engineering, not the named configuration: only the X rows the off-block columns name travel
+            out["variants"] = dict(needed_rows=dict(
+                value=round(flops_total / t_step_other * 1e-9, 2), unit="GFLOP/s", ms_per_step=round(t_step_other * 1e3, 5),
+                rows_received_per_rank=received, bytes_received_per_rank=(received or 0) * k * 8,
+                note="same products as `value`; one all_to_all of the needed X rows instead of the all-gather of all of X "
+                     f"({(world - 1) * rows_local * k * 8} bytes per rank and step)"))
         return out
     return None
 

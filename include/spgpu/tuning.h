@@ -37,9 +37,11 @@ void spgpuTuningReload(void);
  * is avgNnzPerRow, hell.h:45-59).  Every form computes the same values; AUTO, GATHER, STRIPS and XTILE also the same
  * bits (the order in which a row's products are added does not depend on the form).
  *
- *   AUTO    the library decides per matrix: sample wavefronts of every launch report what they saw (consecutive
- *           columns in neighbouring rows / columns inside a window that fits an LDS tile / scattered) and the next
- *           launch on the same arrays uses it.  A first call runs the strip-capable kernel.
+ *   AUTO    the library decides per matrix: sample wavefronts report what they saw (consecutive columns in neighbouring
+ *           rows / columns inside a window that fits an LDS tile / scattered) and the next launch on the same arrays
+ *           uses it.  A first call runs the strip-capable kernel, whose own wavefronts report; the other forms are
+ *           looked at again by a three-wavefront probe with every fourth call (another matrix may have come to live
+ *           at the address).  spgpuHellSpmvForm / spgpuEllSpmvForm below give the same answer at once, to keep.
  *   GATHER  one global load per nonzero.
  *   STRIPS  the x values of a lane's consecutive rows with ONE 16-byte load where those rows name consecutive
  *           columns (stencil and band matrices in natural order); falls back to gathers stage by stage.
@@ -68,6 +70,24 @@ void spgpuSetSpmvForm(spgpuHandle_t handle, int form);
 int spgpuGetSpmvForm(spgpuHandle_t handle);
 /* Diagnostic: the form (GATHER / STRIPS / XTILE / SWEEP) the most recent ELL/HELL SpMV call on this handle was launched in. */
 int spgpuGetLastSpmvForm(spgpuHandle_t handle);
+
+/*
+ * The answer AUTO would settle on for ONE matrix, for a caller who wants to hold it instead of leaving it to AUTO's table
+ * of the eight most recent (rP, rows) pairs -- which learns a call late, and a few calls late when another matrix comes
+ * to live at the address of an old one:
+ *
+ *     form = spgpuHellSpmvForm(handle, SPGPU_TYPE_DOUBLE, rP, hackSize, hackOffsets, rS, rows, baseIndex);   // once per matrix
+ *     spgpuSetSpmvForm(handle, form);  spgpuDhellspmv(handle, ...);                                           // every call
+ *
+ * Three wavefronts look at the column indices of three groups of rows (near the quarter points of the matrix) on the
+ * handle's current stream; the call WAITS for them (it synchronises that stream) and returns SPGPU_SPMV_FORM_STRIPS,
+ * _XTILE or _GATHER (AUTO if the device call failed).  One analysis of a handle at a time.  rP / hackOffsets / rS: the
+ * device arrays of the SpMV call; rS may be NULL for ELL (every row maxNnzPerRow long).
+ */
+int spgpuHellSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int hackSize, const int* hackOffsets, const int* rS, int rows,
+                      int baseIndex);
+int spgpuEllSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int rPPitch, const int* rS, int maxNnzPerRow, int rows,
+                     int baseIndex);
 
 #ifdef __cplusplus
 }

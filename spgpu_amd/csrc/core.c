@@ -70,10 +70,10 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     if (err == hipSuccess)
         err = hipHostMalloc(&h->reduceHost, SPGPU_REDUCE_SCRATCH_BYTES, hipHostMallocDefault);
     if (err == hipSuccess)
-        err = hipHostMalloc((void**)&h->formFeedback, SPGPU_FEEDBACK_ENTRIES * SPGPU_FEEDBACK_SAMPLES * sizeof(int),
+        err = hipHostMalloc((void**)&h->formFeedback, (SPGPU_FEEDBACK_ENTRIES + 1) * SPGPU_FEEDBACK_SAMPLES * sizeof(int),
                             hipHostMallocDefault);
     if (err == hipSuccess)
-        memset(h->formFeedback, 0, SPGPU_FEEDBACK_ENTRIES * SPGPU_FEEDBACK_SAMPLES * sizeof(int));
+        memset(h->formFeedback, 0, (SPGPU_FEEDBACK_ENTRIES + 1) * SPGPU_FEEDBACK_SAMPLES * sizeof(int));
     hipSetDevice(previous);
 
     if (err != hipSuccess) {
@@ -182,7 +182,7 @@ size_t spgpuSizeOf(spgpuType_t typeCode)
     }
 }
 
-int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows)
+int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows, int* calls)
 {
     /* Two host threads may share a handle (the reference documents one handle per thread, core.h:88-90, but does not
      * enforce it): the table is searched and re-assigned under a lock.  The words themselves are written by the GPU
@@ -191,12 +191,16 @@ int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows)
     pthread_mutex_lock(&h->formLock);
     int* slot = NULL;
     for (unsigned e = 0; e < SPGPU_FEEDBACK_ENTRIES && !slot; ++e)
-        if (h->formKey[e] == key && h->formRows[e] == rows)
+        if (h->formKey[e] == key && h->formRows[e] == rows) {
             slot = h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
+            *calls = ++h->formCalls[e];
+        }
     if (!slot) {
         const unsigned e = h->formNext++ % SPGPU_FEEDBACK_ENTRIES; /* oldest entry makes room */
         h->formKey[e] = key;
         h->formRows[e] = rows;
+        h->formCalls[e] = 0;
+        *calls = 0;
         slot = h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
         for (int i = 0; i < SPGPU_FEEDBACK_SAMPLES; ++i)
             slot[i] = 0;
@@ -222,6 +226,11 @@ spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, SpgpuDeepList* list)
     list->partials = base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES;
     list->itemSums = base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES + DEEP_PARTIAL_BYTES;
     return SPGPU_SUCCESS;
+}
+
+int* spgpuAnalyseWords(spgpuHandle_t pHandle)
+{
+    return spgpuPrivate(pHandle)->formFeedback + SPGPU_FEEDBACK_ENTRIES * SPGPU_FEEDBACK_SAMPLES;
 }
 
 /* ---- per-handle kernel-form hint (include/spgpu/tuning.h) ---- */

@@ -547,28 +547,9 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
                 }
             }
         }
-        else if constexpr (RPL > 1 && XPOLICY == 0) {
-            /* gather-only form: the three sample wavefronts still look at their first stage and report, so that a
-             * different matrix that later lives at the same address is recognised (a call or two late) */
-            if (a.feedback) {
-                const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
-                if (group == sampleGroup(groups, 1) || group == sampleGroup(groups, 2) || group == sampleGroup(groups, 3)) {
-                    /* the same measure the strip-capable kernel reports (stages that qualify before the first
-                     * that does not), from a walk over the indices of its own: three wavefronts, outside the loop */
-                    int asStrips = 0;
-                    for (; asStrips < groupLongest; asStrips += STEP) {
-                        Stage probe;
-                        fetch(asStrips, probe);
-                        if (!stageIsStrips(asStrips, probe))
-                            break;
-                    }
-                    const int other = columnSpan() <= a.tileSpanLimit ? 3 : 1;
-                    for (int q = 1; q <= 3; ++q)
-                        if (group == sampleGroup(groups, q) && lane == 0)
-                            a.feedback[q - 1] = 2 * asStrips >= groupLongest && groupLongest > STEP ? 2 : other;
-                }
-            }
-        }
+        /* (the gather-only and x-tile forms do not report: a walk over the sample wavefronts' indices compiled into this
+         * kernel cost its hot loop 7-8 % on scattered columns although three wavefronts ran it -- 1.40 -> 1.51 ms on the
+         * 65 536-wide window pattern, profiles/r03_ab_gather_feedback.txt; formProbeKernel below looks instead) */
         if (!done) {
             /* kBase is wavefront-uniform; saying so keeps the loop counter (and every k derived from it) scalar */
             for (kBase = __builtin_amdgcn_readfirstlane(kBase); kBase < groupLongest; kBase += STEP) {
@@ -851,6 +832,76 @@ __global__ __launch_bounds__(kBlockThreads) void deepFinishKernel(const SlabArgs
 }
 
 /*
+ * What do the columns of this matrix look like?  Three wavefronts (the sample groups of slabSpmvKernel) walk their rows'
+ * indices and report what the strip-capable kernel's samples would: 2 = neighbouring rows name consecutive columns (strip x
+ * loads), 3 = the columns of a group lie inside a window an LDS tile holds, 1 = scattered.  Launched by AUTO with every
+ * fourth call of the forms that do not report themselves, and by spgpu?SpmvForm (include/spgpu/tuning.h) for a caller who
+ * wants to hold the answer.  STEP = the columns per stage of the strip-capable kernel of the type (its strip test is per stage).
+ */
+template <typename T, int RPL, int PH, bool IS_HELL, int STEP>
+__global__ __launch_bounds__(kWave) void formProbeKernel(const SlabArgs<T> a)
+{
+    constexpr int LPC = kWave / PH, GROUP_ROWS = LPC * RPL;
+    const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
+    const long long group = sampleGroup(groups, (int)blockIdx.x + 1);
+    const int lane = threadIdx.x;
+    const long long row0 = group * GROUP_ROWS + (long long)lane * RPL;
+    int len[RPL], longest = 0;
+    long long slab = 0;
+    const bool live = lane < LPC && row0 < a.rows;
+    if (live) {
+        if constexpr (IS_HELL) {
+            const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
+            slab = (long long)a.hackOffsets[r0 / hs] + (r0 % hs);
+        } else {
+            slab = row0;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) {
+        const long long r = row0 + t;
+        len[t] = live && r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
+        longest = len[t] > longest ? len[t] : longest;
+    }
+    const int groupLongest = waveMax(longest);
+    /* first column at which this lane's strip is neither "all rows present with consecutive columns" nor "all past their end" */
+    int firstBad = 0x7fffffff, lowest = 0x7fffffff, highest = -1;
+    bool below = false;
+    for (int k = 0; k < longest; ++k) {
+        const bool present = k < len[0];
+        const int c0 = present ? a.rP[slab + (long long)k * a.idxStride] : 0;
+        bool bad = present && c0 - a.baseIndex < 0;
+#pragma unroll
+        for (int t = 1; t < RPL; ++t) {
+            const bool here = k < len[t];
+            bad |= here != present || (present && a.rP[slab + t + (long long)k * a.idxStride] != c0 + t);
+        }
+        if (bad) {
+            firstBad = k;
+            break;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) { /* the span of the group's columns: first and last entry of every row */
+        if (len[t] > 0) {
+            const int f = a.rP[slab + t] - a.baseIndex, l = a.rP[slab + t + (long long)(len[t] - 1) * a.idxStride] - a.baseIndex;
+            below |= f < 0 || l < 0;
+            lowest = f < lowest ? f : lowest;
+            lowest = l < lowest ? l : lowest;
+            highest = f > highest ? f : highest;
+            highest = l > highest ? l : highest;
+        }
+    }
+    firstBad = waveMin(firstBad);
+    lowest = waveMin(lowest);
+    highest = waveMax(highest);
+    const long long span = __ballot(below) != 0ull ? (1ll << 40) : (highest < lowest ? 0ll : (long long)highest - lowest + 1);
+    const int asStrips = firstBad == 0x7fffffff ? groupLongest : firstBad / STEP * STEP; /* whole stages of strips in front */
+    if (lane == 0 && a.feedback)
+        a.feedback[blockIdx.x] = (RPL > 1 && 2 * asStrips >= groupLongest && groupLongest > STEP) ? 2 : (span <= a.tileSpanLimit ? 3 : 1);
+}
+
+/*
  * SWEEP form (include/spgpu/tuning.h; chosen by the caller, never by AUTO): for matrices whose columns are scattered over
  * all of x but ascend inside a row.  A lane owns PACKS packs of VEC neighbouring rows (32 rows for 4- and 8-byte elements)
  * and carries all of them through the slab columns in step; the grid is small enough to be resident at once and walks
@@ -1048,6 +1099,23 @@ static void launchDeep(hipStream_t stream, const SlabArgs<T>& a)
     hipLaunchKernelGGL((deepFinishKernel<T>), dim3(256), dim3(kBlockThreads), 0, stream, a);
 }
 
+/* The probe of the type's default kernel shape (launchSlabFamily): D/C walk whole rows, 8 columns per stage; S 8 phases x 2. */
+template <typename T, bool IS_HELL>
+static void launchFormProbe(hipStream_t stream, const SlabArgs<T>& a, bool wideOk)
+{
+    constexpr int WIDE = 16 / (int)sizeof(T);
+    if constexpr (WIDE > 1) {
+        if (wideOk) {
+            if constexpr (sizeof(T) == 4)
+                hipLaunchKernelGGL((formProbeKernel<T, WIDE, 2 * WIDE, IS_HELL, 2 * WIDE * 2>), dim3(3), dim3(kWave), 0, stream, a);
+            else
+                hipLaunchKernelGGL((formProbeKernel<T, WIDE, 1, IS_HELL, 8>), dim3(3), dim3(kWave), 0, stream, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((formProbeKernel<T, 1, 2, IS_HELL, 8>), dim3(3), dim3(kWave), 0, stream, a);
+}
+
 template <typename T, bool IS_HELL>
 static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
 {
@@ -1180,14 +1248,15 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             launchDeep<T, WIDE, IS_HELL>(stream, a);
         return;
     }
-    bool strips = false, autoTile = false;
+    bool strips = false, autoTile = false, probeBehind = false;
     a.feedback = nullptr;
     a.tileSpanLimit = (long long)(32768 / sizeof(T)) * 5 / 4; /* 1.25 x the default tile (launchTiled, shape 0) */
     if (!narrowVariant && WIDE > 1 && !tiled) {
         if (form != SPGPU_SPMV_FORM_AUTO) {
             strips = form == SPGPU_SPMV_FORM_STRIPS;
         } else {
-            int* seen = spgpuFormFeedback(handle, a.rP, a.rows);
+            int calls = 0;
+            int* seen = spgpuFormFeedback(handle, a.rP, a.rows, &calls);
             int gathers = 0, local = 0;
             for (int q = 0; q < 3; ++q) {
                 const int said = ((volatile int*)seen)[q];
@@ -1198,11 +1267,18 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
              * nothing known yet) the strip-capable kernel */
             autoTile = local >= 2 && tune->spmvVariant < 1 && (variant == 21 || variant == 22);
             strips = gathers + local < 2;
-            a.feedback = seen; /* every form reports: the matrix at this address may be another one next time */
+            a.feedback = seen; /* the strip-capable kernel's sample wavefronts report (it is what a new matrix runs first) */
+            /* the other forms do not (see slabSpmvKernel): with every fourth call of theirs three wavefronts look at the
+             * matrix again -- another one may live at this address by now */
+            probeBehind = !strips && calls % 4 == 0;
         }
     }
 
     spgpuNoteSpmvForm(handle, (tiled || autoTile) ? SPGPU_SPMV_FORM_XTILE : (strips ? SPGPU_SPMV_FORM_STRIPS : SPGPU_SPMV_FORM_GATHER));
+    if (probeBehind)
+        launchFormProbe<T, IS_HELL>(stream, a, wideOk); /* 3 wavefronts; its answer is for later calls */
+    if (!strips)
+        a.feedback = nullptr;
     if (!narrowVariant) {
         a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
         if constexpr (WIDE > 1) {
@@ -1360,11 +1436,71 @@ static void ellCsput(spgpuHandle_t handle, ApiT* cM, const int* rP, int cMPitch,
     spgpuDebugCheck(handle, "ellcsput");
 }
 
+
+/* ---- spgpuHellSpmvForm / spgpuEllSpmvForm (include/spgpu/tuning.h): the probe, synchronously ---- */
+template <typename T, bool IS_HELL>
+static int analyseForm(spgpuHandle_t handle, const int* rP, int hackSize, const int* hackOffsets, long long idxStride, const int* rS,
+                       int maxNnz, int rows, int baseIndex)
+{
+    if (rows <= 0)
+        return SPGPU_SPMV_FORM_GATHER;
+    constexpr int WIDE = 16 / (int)sizeof(T);
+    SlabArgs<T> a{};
+    a.rP = rP;
+    a.rS = rS;
+    a.hackOffsets = hackOffsets;
+    a.rows = rows;
+    a.baseIndex = baseIndex;
+    a.hackSize = hackSize;
+    a.maxNnz = maxNnz;
+    a.idxStride = idxStride;
+    a.valStride = idxStride;
+    a.tileSpanLimit = (long long)(32768 / sizeof(T)) * 5 / 4;
+    int* seen = spgpuAnalyseWords(handle);
+    seen[0] = seen[1] = seen[2] = 0;
+    a.feedback = seen;
+    const bool wide = IS_HELL ? (hackSize > 0 && hackSize % WIDE == 0) : true;
+    launchFormProbe<T, IS_HELL>(handle->currentStream, a, wide);
+    if (hipStreamSynchronize(handle->currentStream) != hipSuccess)
+        return SPGPU_SPMV_FORM_AUTO;
+    int strips = 0, local = 0;
+    for (int q = 0; q < 3; ++q) {
+        strips += seen[q] == 2;
+        local += seen[q] == 3;
+    }
+    return strips >= 2 ? SPGPU_SPMV_FORM_STRIPS : (local >= 2 ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
+}
+
+template <bool IS_HELL>
+static int analyseFormOfType(spgpuHandle_t handle, spgpuType_t type, const int* rP, int hackSize, const int* hackOffsets, long long idxStride,
+                             const int* rS, int maxNnz, int rows, int baseIndex)
+{
+    switch (type) {
+    case SPGPU_TYPE_FLOAT: return analyseForm<float, IS_HELL>(handle, rP, hackSize, hackOffsets, idxStride, rS, maxNnz, rows, baseIndex);
+    case SPGPU_TYPE_DOUBLE: return analyseForm<double, IS_HELL>(handle, rP, hackSize, hackOffsets, idxStride, rS, maxNnz, rows, baseIndex);
+    case SPGPU_TYPE_COMPLEX_FLOAT: return analyseForm<cfloat, IS_HELL>(handle, rP, hackSize, hackOffsets, idxStride, rS, maxNnz, rows, baseIndex);
+    case SPGPU_TYPE_COMPLEX_DOUBLE: return analyseForm<cdouble, IS_HELL>(handle, rP, hackSize, hackOffsets, idxStride, rS, maxNnz, rows, baseIndex);
+    default: return SPGPU_SPMV_FORM_AUTO;
+    }
+}
+
 } // namespace spgpu
 
 using namespace spgpu;
 
 extern "C" {
+
+int spgpuHellSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int hackSize, const int* hackOffsets, const int* rS, int rows,
+                      int baseIndex)
+{
+    return analyseFormOfType<true>(handle, type, rP, hackSize, hackOffsets, hackSize, rS, 0, rows, baseIndex);
+}
+
+int spgpuEllSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int rPPitch, const int* rS, int maxNnzPerRow, int rows,
+                     int baseIndex)
+{
+    return analyseFormOfType<false>(handle, type, rP, 0, nullptr, rPPitch, rS, maxNnzPerRow, rows, baseIndex);
+}
 
 #ifdef SPGPU_TRACE_BLOCKS
 void spgpuDebugSetTrace(unsigned long long* buffer)

@@ -30,6 +30,7 @@ typedef struct SpgpuPrivateHandle {
     int* formFeedback;                              /* pinned, SPGPU_FEEDBACK_ENTRIES * SPGPU_FEEDBACK_SAMPLES ints */
     const void* formKey[8];
     int formRows[8];
+    int formCalls[8];                               /* SpMV calls seen for the entry */
     unsigned formNext;
     pthread_mutex_t formLock; /* guards formKey / formRows / formNext */
     int spmvForm;             /* SPGPU_SPMV_FORM_* set by spgpuSetSpmvForm (atomic) */
@@ -40,7 +41,7 @@ typedef struct SpgpuPrivateHandle {
     int deepStreams;
     int lastSpmvForm;         /* form of the most recent ELL/HELL SpMV launch (diagnostic, atomic) */
 } SpgpuPrivateHandle;
-#define SPGPU_FEEDBACK_ENTRIES 8
+#define SPGPU_FEEDBACK_ENTRIES 8 /* + one more group of words behind them for spgpu?SpmvForm */
 #define SPGPU_FEEDBACK_SAMPLES 4
 
 static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
@@ -83,8 +84,9 @@ void spgpuDebugCheck(spgpuHandle_t h, const char* what);
 
 void spgpuNoteSpmvForm(spgpuHandle_t h, int form);
 
-/* The feedback ints of the matrix identified by (key, rows): found or newly assigned (and zeroed). */
-int* spgpuFormFeedback(spgpuHandle_t h, const void* key, int rows);
+/* The feedback ints of the matrix identified by (key, rows): found or newly assigned (and zeroed); *calls = how many
+ * SpMV calls have asked for this entry before. */
+int* spgpuFormFeedback(spgpuHandle_t h, const void* key, int rows, int* calls);
 
 /* Environment knobs (include/spgpu/tuning.h), read once and cached: no getenv in a launch path. */
 typedef struct SpgpuTuning {
@@ -108,6 +110,9 @@ typedef struct SpgpuTuning {
     int l1Nt;        /* -1: by size */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);
+
+/* Pinned words for the synchronous analysis calls (spgpuHellSpmvForm / spgpuEllSpmvForm): one analysis of a handle at a time. */
+int* spgpuAnalyseWords(spgpuHandle_t h);
 
 #ifdef __cplusplus
 }

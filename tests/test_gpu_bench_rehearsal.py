@@ -28,9 +28,12 @@ def test_two_ranks_on_one_gpu(gpu, exchange, pattern):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["unit"] == "GFLOP/s"
     assert "MISMATCH" not in out["parity"] and "oracle" in out["parity"]
     assert out["config"]["rows_total"] == 400000
+    assert "SpMM" in out["metric"] and "2 GPUs" in out["metric"]
     if exchange == "needed":
         assert out["spmm"]["needed_rows_received_per_rank"] == 31        # 16 rows below the block, 15 above (wrapped band)
-        assert out["spmm"]["allgather_step_ms"] > 0
+        assert out["spmm"]["allgather_step_ms"] > 0 and out["as_named_allgather"]["value"] > 0
+    else:   # the named configuration leads; the needed-rows exchange is measured beside it
+        assert "all-gather" in out["config"]["exchange"] and out["variants"]["needed_rows"]["value"] > 0
 
 
 def test_gpus_two_direct_form(gpu):
@@ -47,3 +50,4 @@ def test_gpus_two_direct_form(gpu):
     assert len(lines) == 1, run.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["rows_total"] == 200000 and "MISMATCH" not in out["parity"]
+    assert out["config"]["exchange"] == "all-gather"      # BASELINE configs[4] as named is the default

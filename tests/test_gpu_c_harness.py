@@ -28,6 +28,21 @@ def test_hellperf_flow(pattern, precision):
     assert "checksums identical: PASSED" in out and "OELL checksum equal within rounding: PASSED" in out
 
 
+@pytest.mark.parametrize("pattern,precision", [("banded", "s"), ("random", "d")])
+def test_hellperf_norowsize_flow(pattern, precision):
+    """The reference's hellperf_norowsize_{s,d} executables (-DNO_ROW_SIZE, src/CMakeLists.txt:186-188,
+    hellPerf.cpp:200-204): the ELL run with rS == NULL walks every row to maxRowSize over the converter's zero padding and
+    must print the checksum of the HELL run (which has its row sizes)."""
+    out = _run("hellperf_amd", 150000, 12, pattern, 10, precision, "norowsize")
+    assert "ELL (rS == NULL) dot res" in out and "checksums identical: PASSED" in out
+
+
+def test_cg_timing_only_flag_keeps_the_bit_checks():
+    """bench.py's call: a fixed number of iterations far from convergence; the graph runs must still repeat the eager run."""
+    out = _run("cg_amd", 256, 20, 1e-30, "timing")
+    assert "PASSED" in out and out.count("bit-identical to the eager run") == 2
+
+
 @pytest.mark.parametrize("precision", ["d", "s"])
 def test_hellperf_on_a_matrix_market_file(tmp_path, precision):
     """The reference harness's real input path: a symmetric coordinate file (lower triangle stored) is read, unfolded,

@@ -273,3 +273,85 @@ def test_full_size_c3_hell_fp32_power_law(gpu):
             exact, scale = _exact_rows(vals, cols, lens, xs)
             err = np.abs(z[hack * 32:(hack + 1) * 32].cpu().numpy().astype(np.longdouble) - exact)
             assert np.all(err <= 1e-4 * scale + np.finfo(np.float32).tiny)
+
+
+def test_full_size_c3_ell_fp32_power_law(gpu):
+    """The ELL half of BASELINE configs[2] at its full size: 10 M rows of power-law lengths (max 2048) as ELL are
+    pitch x 2048 slots = 164 GB of coefficients and indices (the HELL of the same rows: 12.8 GB).  Built in HBM, run through
+    spgpuSellspmv (slot index r + k * pitch exceeds 2^31: 64-bit index arithmetic), rows of the first, a middle and the last
+    hack against sums in 64-bit-mantissa arithmetic formed from the stored slots."""
+    import torch
+    from spgpu_amd import capi, synth
+    n = 10_000_000
+    lengths = synth.power_law_lengths(n, mean=32.0, max_len=2048, seed=5)
+    free, _ = torch.cuda.mem_get_info()
+    pitch, deepest = (n + 31) // 32 * 32, int(lengths.max())
+    need = pitch * deepest * 8
+    if free < need + (4 << 30):
+        pytest.skip(f"needs {need / 1e9:.0f} GB of free device memory, {free / 1e9:.0f} GB free")
+    e = synth.ell_ragged_on_device(lengths, n, "S", seed=6)
+    assert e["pitch"] * e["max_row"] > 2**31
+    x = synth.device_vector(n, "S", 3)
+    z = torch.empty(n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    capi.ellspmv["S"](gpu, _p(z), None, 1.0, _p(e["cM"]), _p(e["rP"]), e["pitch"], e["pitch"], _p(e["rS"]), None, 32, e["max_row"], n,
+                      _p(x), 0.0, 0)
+    torch.cuda.synchronize()
+    xs = x.cpu().numpy()
+    got = z.cpu().numpy()
+    longest = int(np.argmax(lengths))
+    for first in (0, longest // 32 * 32, 5_000_000 // 32 * 32, n - 32):
+        rows = torch.arange(first, first + 32, device="cuda", dtype=torch.int64)
+        depth = int(lengths[first:first + 32].max())
+        slots = rows[:, None] + torch.arange(depth, device="cuda", dtype=torch.int64)[None, :] * e["pitch"]
+        vals, cols = e["cM"][slots].cpu().numpy(), e["rP"][slots].cpu().numpy()
+        exact, scale = _exact_rows(vals, cols, lengths[first:first + 32], xs)
+        err = np.abs(got[first:first + 32].astype(np.longdouble) - exact)
+        assert np.all(err <= TOL["S"] * scale + np.finfo(np.float32).tiny), first
+    del e
+    torch.cuda.empty_cache()
+
+
+def test_full_size_spmm_shard_of_configs4(gpu):
+    """The single-GPU slice of BASELINE configs[4]: 5 M rows x 32 nnz x 16 right-hand sides, fp64, through spgpuDhellspmm;
+    windows of rows against sums in 64-bit-mantissa arithmetic formed from the stored slots (every right-hand side)."""
+    import torch
+    from spgpu_amd import capi, synth
+    n, L, k = 5_000_000, 32, 16
+    h = synth.hell_uniform_on_device(n, L, "banded", "D", 32, seed=11)
+    X = synth.device_vector(n * k, "D", 21).view(n, k)
+    Z = torch.empty_like(X)
+    torch.cuda.synchronize()
+    capi.hellspmm["D"](gpu, _p(Z), None, C.c_double(1.0), _p(h["cM"]), _p(h["rP"]), 32, _p(h["hack_offsets"]), _p(h["rS"]), None, L, n,
+                       _p(X), C.c_double(0.0), 0, k, k, k)
+    torch.cuda.synchronize()
+    for first in (0, 2_500_000 // 2048 * 2048, n - 2048):
+        vals, cols, _ = _hell_window(h, first, 2048)
+        xs = X[torch.from_numpy(cols.astype(np.int64)).cuda()].cpu().numpy().astype(np.longdouble)      # [rows][L][k]
+        prod = vals.astype(np.longdouble)[:, :, None] * xs
+        exact, scale = prod.sum(axis=1), np.abs(prod).sum(axis=1)
+        err = np.abs(Z[first:first + 2048].cpu().numpy().astype(np.longdouble) - exact)
+        assert np.all(err <= TOL["D"] * scale), first
+
+
+def test_configs0_laplacian_1024_through_the_host_converters(gpu):
+    """BASELINE configs[0] on the GPU: 5-point Laplacian 1024 x 1024 (1 048 576 rows), COO -> cooToEll -> ellToHell on the
+    host, uploaded, spgpuDhellspmv with alpha = 2, beta = -3 (the coefficients of the reference's ctest.c): every row
+    against the oracle bit for bit, and against the stencil evaluated directly."""
+    import torch
+    from spgpu_amd import formats, synth
+    n, m, r, c, v = synth.laplacian_2d_5pt(1024)
+    hell = formats.ell_to_hell(formats.coo_to_ell(n, r, c, v), 32)
+    x, y = synth.hashed_vector(m), synth.hashed_vector(n, multiplier=40503)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    dz = torch.empty_like(dy)
+    formats.DeviceHell(hell).spmv(gpu, dz, dy, 2.0, dx, -3.0)
+    torch.cuda.synchronize()
+    got = dz.cpu().numpy()
+    assert got.tobytes() == O.default_spmv(hell, x, y, 2.0, -3.0).tobytes()
+    acc = np.zeros(n, np.longdouble)
+    np.add.at(acc, r, v.astype(np.longdouble) * x.astype(np.longdouble)[c])
+    mag = np.zeros(n, np.longdouble)
+    np.add.at(mag, r, np.abs(v.astype(np.longdouble) * x.astype(np.longdouble)[c]))
+    want = 2 * acc - 3 * y.astype(np.longdouble)
+    assert np.all(np.abs(got.astype(np.longdouble) - want) <= 1e-6 * (2 * mag + 3 * np.abs(y)))

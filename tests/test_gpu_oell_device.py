@@ -315,7 +315,7 @@ def test_auto_form_settles_on_the_matrix(gpu, pattern, expect):
     torch.cuda.synchronize()
     capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
     results = []
-    for _ in range(4):
+    for _ in range(10):     # the arrays may sit where the previous case's did: the forms that do not report are probed every 4th call
         capi.hellspmv["D"](gpu, _dp(z), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), None, 32, n,
                            _dp(x), 0.0, 0)
         torch.cuda.synchronize()
@@ -473,3 +473,72 @@ def test_more_streams_than_deep_lists(gpu):
     finally:
         capi.spgpuSetStream(handle, None)
         capi.spgpuDestroy(handle)
+
+
+@pytest.mark.parametrize("pattern,expect", [("banded", "strips"), ("near512", "xtile"), ("random", "gather")])
+@pytest.mark.parametrize("letter", ["D", "S"])
+def test_analysis_call_gives_the_form_at_once(gpu, pattern, expect, letter):
+    """spgpuHellSpmvForm / spgpuEllSpmvForm: the answer AUTO settles on, synchronously, for a caller who holds it --
+    consecutive columns -> strips, columns inside a window an LDS tile holds -> x-tile, scattered -> gathers; the SpMV run
+    in that form gives the bits of the default run."""
+    import torch
+    from spgpu_amd import capi, synth
+    n = 200_000
+    h = synth.hell_uniform_on_device(n, 32, pattern, letter, 32, seed=3)
+    x = synth.device_vector(n, letter, 5)
+    z, z2 = torch.empty_like(x), torch.empty_like(x)
+    torch.cuda.synchronize()
+    want = {"strips": capi.FORM_STRIPS, "xtile": capi.FORM_XTILE, "gather": capi.FORM_GATHER}[expect]
+    form = capi.spgpuHellSpmvForm(gpu, capi.TYPE_CODE[letter], _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), n, 0)
+    assert form == want
+    # the same slots as ELL (uniform rows: pitch = n)
+    rP_ell = h["rP"].view(n // 32, 32, 32).permute(1, 0, 2).reshape(-1).contiguous()
+    torch.cuda.synchronize()
+    assert capi.spgpuEllSpmvForm(gpu, capi.TYPE_CODE[letter], _dp(rP_ell), n, None, 32, n, 0) == want
+    one, zero = capi.scalar(letter, 1.0), capi.scalar(letter, 0.0)
+    call = lambda out: capi.hellspmv[letter](gpu, _dp(out), None, one, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]),
+                                             None, 32, n, _dp(x), zero, 0)
+    capi.spgpuSetSpmvForm(gpu, form)
+    try:
+        call(z)
+        torch.cuda.synchronize()
+        assert capi.spgpuGetLastSpmvForm(gpu) == want
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    for _ in range(3):
+        call(z2)
+        torch.cuda.synchronize()
+    assert torch.equal(z, z2)
+
+
+def test_auto_notices_another_matrix_at_the_same_address(gpu):
+    """AUTO's table is keyed by (rP, rows): when a scattered matrix is overwritten in place by a banded one, the gather
+    form -- which does not report by itself -- is looked at again by the probe with every fourth call, and the
+    strip form takes over; results stay the oracle's throughout."""
+    import torch
+    from spgpu_amd import capi, synth
+    n = 100_000
+    scattered = synth.hell_uniform_on_device(n, 32, "random", "D", 32, seed=3)
+    banded = synth.hell_uniform_on_device(n, 32, "banded", "D", 32, seed=4)
+    x = synth.device_vector(n, "D", 5)
+    z = torch.empty_like(x)
+    torch.cuda.synchronize()
+    h = scattered
+    call = lambda: capi.hellspmv["D"](gpu, _dp(z), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), None, 32,
+                                      n, _dp(x), 0.0, 0)
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    for _ in range(3):
+        call()
+        torch.cuda.synchronize()
+    assert capi.spgpuGetLastSpmvForm(gpu) == capi.FORM_GATHER
+    h["rP"].copy_(banded["rP"])          # another matrix, same arrays
+    h["cM"].copy_(banded["cM"])
+    torch.cuda.synchronize()
+    forms = []
+    for _ in range(40):
+        call()
+        torch.cuda.synchronize()
+        forms.append(capi.spgpuGetLastSpmvForm(gpu))
+    assert forms[-1] == capi.FORM_STRIPS and capi.FORM_STRIPS in forms[:10]
+    sub = synth.hell_rows_to_host(h, 0, 2048)
+    assert z[:2048].cpu().numpy().tobytes() == O.default_spmv(sub, x.cpu().numpy(), None, 1.0, 0.0).tobytes()

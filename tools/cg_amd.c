@@ -6,7 +6,9 @@
  * captured into a HIP graph (6 kernels, no host round trip; two copies that alternate the |r|^2 cell) and replayed; the iterate must come out bit for bit
  * the same as in the eager run.
  *
- *   usage: cg_amd [grid=1024] [maxIter=200] [tol=1e-8]
+ *   usage: cg_amd [grid=1024] [maxIter=200] [tol=1e-8] [timing]
+ *   timing: the caller only wants the per-iteration times of a fixed number of iterations (bench.py: 60 of them): the
+ *   convergence criterion of the self-check is waived, the graph runs must still repeat the eager run bit for bit
  * Prints the residual history and time per iteration; exits non-zero if the residual does not fall or the two
  * runs differ.
  */
@@ -36,6 +38,7 @@ int main(int argc, char** argv)
     const int g = argc > 1 ? atoi(argv[1]) : 1024;
     const int maxIter = argc > 2 ? atoi(argv[2]) : 200;
     const double tol = argc > 3 ? atof(argv[3]) : 1e-8;
+    const int timingOnly = argc > 4 && strcmp(argv[4], "timing") == 0;
     const int n = g * g, hackSize = 32;
 
     /* 5-point Laplacian in COO, natural order */
@@ -203,7 +206,8 @@ int main(int argc, char** argv)
 
     spgpuDestroy(h);
     CHECK(hipGetLastError());
-    const int ok = rr < rr0 && same && sameFused;
-    printf(ok ? "PASSED\n" : "FAILED (residual did not fall, or a graph run differs)\n");
+    const int converged = rr < rr0 * 1e-4 || sqrt(rr / rr0) <= tol;
+    const int ok = (timingOnly ? rr < rr0 : converged) && same && sameFused;
+    printf(ok ? "PASSED\n" : "FAILED (residual did not reach the tolerance, or a graph run differs)\n");
     return ok ? 0 : 1;
 }

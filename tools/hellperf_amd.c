@@ -6,8 +6,11 @@
  * matrix (no .mtx ships with the reference), and with HIP in place of the CUDA runtime.  alpha = 1, beta = 0 as hellPerf.cpp:27-28.  Adds what the reference's harness
  * lacks: the two dot(z,z) are compared, and achieved HBM GB/s is printed next to GFlop/s.
  *
- *   usage: hellperf_amd [rows=1000000] [nnzPerRow=32] [banded|random] [reps=200] [s|d]
- *          hellperf_amd matrix.mtx [reps=200] [s|d]
+ *   usage: hellperf_amd [rows=1000000] [nnzPerRow=32] [banded|random] [reps=200] [s|d] [norowsize]
+ *          hellperf_amd matrix.mtx [reps=200] [s|d] [norowsize]
+ * norowsize: the ELL run gets rS == NULL -- the reference builds that as separate executables (hellperf_norowsize_s/_d:
+ * -DNO_ROW_SIZE, src/CMakeLists.txt:186-188, hellPerf.cpp:200-204); every row is then walked to maxRowSize over cooToEll's
+ * zero padding, and the result must equal the run with row sizes.
  */
 #include <math.h>
 #include <stdint.h>
@@ -82,6 +85,8 @@ int main(int argc, char** argv)
     const int reps = fromFile ? (argc > 2 ? atoi(argv[2]) : 200) : (argc > 4 ? atoi(argv[4]) : 200);
     const char* prec = fromFile ? (argc > 3 ? argv[3] : "d") : (argc > 5 ? argv[5] : "d");
     const int dbl = prec[0] != 's';
+    const char* last = argc > 1 ? argv[argc - 1] : "";
+    const int noRowSize = strcmp(last, "norowsize") == 0; /* hellPerf.cpp:200-204 */
     const size_t es = dbl ? sizeof(double) : sizeof(float);
     const spgpuType_t type = dbl ? SPGPU_TYPE_DOUBLE : SPGPU_TYPE_FLOAT;
     const int hackSize = 32; /* hellPerf.cpp:254 */
@@ -159,8 +164,8 @@ int main(int argc, char** argv)
     for (int format = 0; format < 2; ++format) {
 #define RUN()                                                                                                   \
         do {                                                                                                    \
-            if (format == 0 && dbl)  spgpuDellspmv(h, dZ, dY, 1.0, dEllV, dEllI, pitch, pitch, dRs, NULL, perRow, maxRow, rows, dX, 0.0, 0); \
-            if (format == 0 && !dbl) spgpuSellspmv(h, dZ, dY, 1.0f, dEllV, dEllI, pitch, pitch, dRs, NULL, perRow, maxRow, rows, dX, 0.0f, 0); \
+            if (format == 0 && dbl)  spgpuDellspmv(h, dZ, dY, 1.0, dEllV, dEllI, pitch, pitch, noRowSize ? NULL : dRs, NULL, perRow, maxRow, rows, dX, 0.0, 0); \
+            if (format == 0 && !dbl) spgpuSellspmv(h, dZ, dY, 1.0f, dEllV, dEllI, pitch, pitch, noRowSize ? NULL : dRs, NULL, perRow, maxRow, rows, dX, 0.0f, 0); \
             if (format == 1 && dbl)  spgpuDhellspmv(h, dZ, dY, 1.0, dHellV, dHellI, hackSize, dHack, dRs, NULL, maxRow, rows, dX, 0.0, 0); \
             if (format == 1 && !dbl) spgpuShellspmv(h, dZ, dY, 1.0f, dHellV, dHellI, hackSize, dHack, dRs, NULL, maxRow, rows, dX, 0.0f, 0); \
         } while (0)
@@ -174,7 +179,7 @@ int main(int argc, char** argv)
         float ms = 0;
         CHECK(hipEventElapsedTime(&ms, t0, t1));
         const double t = ms * 1e-3 / reps;
-        printf("%s dot res: %.10e | %.4f ms | %.1f GFlop/s | %.1f GB/s (%.1f%% of 8 TB/s)\n", format ? "HELL" : "ELL ",
+        printf("%s dot res: %.10e | %.4f ms | %.1f GFlop/s | %.1f GB/s (%.1f%% of 8 TB/s)\n", format ? "HELL" : (noRowSize ? "ELL (rS == NULL)" : "ELL "),
                dots[format], t * 1e3, 2.0 * nnz / t * 1e-9, bytes / t * 1e-9, bytes / t * 1e-9 / 80.0);
     }
     /* ---- third format of the reference's harness: ordered ELL (hellPerf.cpp:320-378).  ellToOell on the host, the
