@@ -31,6 +31,9 @@ extern "C" {
 #endif
 
 void spgpuTuningReload(void);
+/* 1 if the library was built with -DSPGPU_TUNING_VARIANTS: the non-default kernel shapes (SPGPU_SPMV_VARIANT, SPGPU_X_TILE_SHAPE,
+ * SPGPU_RAGGED_SHAPE, SPGPU_RAGGED=0) exist only in such a build; the product build carries the defaults and ignores those knobs. */
+int spgpuTuningVariantsBuilt(void);
 
 /*
  * Per-handle hint: how the ELL/HELL SpMV kernels fetch x (no counterpart in the reference, whose only per-call hint

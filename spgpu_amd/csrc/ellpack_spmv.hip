@@ -1047,6 +1047,7 @@ static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
     constexpr int PH1 = (sizeof(T) == 16 && !DEEP) ? 2 : 1; /* 16-byte elements keep the 2-phase shape of their default kernel */
     constexpr bool TAIL = PH1 == 1;
     switch (shape) {
+#ifdef SPGPU_TUNING_VARIANTS
     case 1:
         if constexpr (!DEEP) {
             launchShape<T, RPL, (RPL > 1 ? 2 * RPL : 2), IS_HELL, (RPL > 1 ? 2 : 4), (RPL > 1), 512, 65536, false>(stream, a);
@@ -1057,6 +1058,7 @@ static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
     case 3: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 49152, DEEP, 2>(stream, a); break;
     case 4: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 256, 65536, DEEP, 2>(stream, a); break;
     case 5: launchShape<T, RPL, PH1, IS_HELL, 4, TAIL, 512, 65536, DEEP, 2>(stream, a); break;
+#endif
     default:
         /* the default: same summation order as the type's gather / strip kernel (launchSlabFamily), so that the form
          * AUTO settles on never changes a bit of the result: 8-byte elements walk whole rows and consider the tail every
@@ -1149,6 +1151,9 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     a.tailLanes = tune->tailLanes >= 0 ? tune->tailLanes : kTailLanes;
     int variant = tune->spmvVariant;
     const bool nt = tune->ntLoads != 0;
+#ifndef SPGPU_TUNING_VARIANTS
+    variant = 0; /* the product build carries the default shapes only (13, 21, 22); the others: -DSPGPU_TUNING_VARIANTS */
+#endif
     if (variant < 1 || variant > 24)
         variant = !wideOk ? 13 : (sizeof(T) == 4 ? 22 : 21);
     const bool narrowVariant = variant == 3 || variant == 4 || (variant >= 13 && variant <= 16);
@@ -1224,7 +1229,12 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     /* ELL says how long its longest row is: when none can exceed the cap nothing registers and the two launches behind
      * the main kernel (~5 us each when empty) are left out; HELL does not say */
     const bool deepPossible = IS_HELL || a.maxNnz > a.deepCap;
-    if (deepSplit && tune->ragged != 0) {
+#ifndef SPGPU_TUNING_VARIANTS
+    constexpr bool queueKernelOnly = true; /* the deep split with fixed rows per wavefront (SPGPU_RAGGED=0) is a lab shape */
+#else
+    constexpr bool queueKernelOnly = false;
+#endif
+    if (deepSplit && (tune->ragged != 0 || queueKernelOnly)) {
         /* the queue-driven kernel for rows ordered by length (ragged_spmv.hip.h); x through an LDS tile unless the
          * caller asked for plain gathers */
         a.wideIO = 0;
@@ -1235,6 +1245,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             launchDeep<T, WIDE, IS_HELL>(stream, a);
         return;
     }
+#ifdef SPGPU_TUNING_VARIANTS
     if (deepSplit) {
         /* shapes in which a lane walks whole rows, for every type; the strip form does not apply to ordered rows */
         a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
@@ -1248,6 +1259,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             launchDeep<T, WIDE, IS_HELL>(stream, a);
         return;
     }
+#endif
     bool strips = false, autoTile = false, probeBehind = false;
     a.feedback = nullptr;
     a.tileSpanLimit = (long long)(32768 / sizeof(T)) * 5 / 4; /* 1.25 x the default tile (launchTiled, shape 0) */
@@ -1283,10 +1295,13 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
         if constexpr (WIDE > 1) {
             switch (variant) {
+#ifdef SPGPU_TUNING_VARIANTS
             case 1: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2>(stream, a, nt); break;
             case 2: launchSlab<T, WIDE, 1, IS_HELL, 4>(stream, a, nt); break;
             case 6: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true>(stream, a, nt); break;
-#ifdef SPGPU_TUNING_VARIANTS
+            case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
+            case 17: launchSlab<T, WIDE, 1, IS_HELL, 8, 1, true>(stream, a, nt); break;
+            case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;
             case 5: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 4>(stream, a, nt); break;
             case 7: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 4, true>(stream, a, nt); break;
             case 8: launchSlab<T, WIDE, 1, IS_HELL, 4, true>(stream, a, nt); break;
@@ -1298,8 +1313,6 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             case 19: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true, 1>(stream, a, nt); break; /* 17 + nt x gathers */
             case 20: launchSlab<T, WIDE, 1, IS_HELL, 8, true, true, 2>(stream, a, nt); break; /* 17 + sc1 x gathers */
 #endif
-            case 12: launchSlab<T, WIDE, 1, IS_HELL, 8, true>(stream, a, nt); break;
-            case 17: launchSlab<T, WIDE, 1, IS_HELL, 8, 1, true>(stream, a, nt); break;
             case 22:
                 if (tiled || autoTile)
                     launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
@@ -1308,7 +1321,6 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
                 else
                     launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true>(stream, a, nt);
                 break;
-            case 18: launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, true, true>(stream, a, nt); break;
             default: /* 21 */
                 if (tiled || autoTile)
                     launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
@@ -1323,9 +1335,9 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     }
     a.wideIO = 1; /* RPL == 1: element access is always aligned */
     switch (variant) {
+#ifdef SPGPU_TUNING_VARIANTS
     case 3: launchSlab<T, 1, 2, IS_HELL, 4>(stream, a, nt); break;
     case 4: launchSlab<T, 1, 1, IS_HELL, 4>(stream, a, nt); break;
-#ifdef SPGPU_TUNING_VARIANTS
     case 14: launchSlab<T, 1, 1, IS_HELL, 8, true>(stream, a, nt); break;
     case 15: launchSlab<T, 1, 2, IS_HELL, 8>(stream, a, nt); break;
     case 16: launchSlab<T, 1, 4, IS_HELL, 2, true>(stream, a, nt); break;
@@ -1489,6 +1501,15 @@ static int analyseFormOfType(spgpuHandle_t handle, spgpuType_t type, const int* 
 using namespace spgpu;
 
 extern "C" {
+
+int spgpuTuningVariantsBuilt(void)
+{
+#ifdef SPGPU_TUNING_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int spgpuHellSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int hackSize, const int* hackOffsets, const int* rS, int rows,
                       int baseIndex)

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
     __shared__ int lens[ROWS];        /* row lengths as walked here (deep sub-groups: cut at deepCap) */
     __shared__ int dests[ROWS];       /* rIdx of the workgroup's rows: fetched from global memory at the end of a sub-group it would be
                                          waited for with vmcnt(0) -- counters retire in order -- and drain the wavefront's prefetch */
-    __shared__ int bases[ROWS / RPL]; /* first slot of every RPL-row strip, in elements */
+    __shared__ unsigned bases[ROWS / RPL]; /* first slot of every RPL-row strip, in elements (hackOffsets is an int array: a slot
+                                              number plus the offset inside the hack fits 32 unsigned bits; 64-bit from here on) */
     __shared__ int depths[SUBS];      /* longest walked row of every sub-group */
     __shared__ int deepSlots[SUBS];   /* its entry in the deep list, or -1 */
     __shared__ int nextItem;
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
      * loads, together with the first stages of the stream.  Measured with 4 round trips and 4 barriers: 12.7 us, a
      * third of a workgroup's life (profiles/r02b_ragged_workgroup_trace.txt). ------------------------------------- */
     constexpr int RPT = (ROWS + BLOCK - 1) / BLOCK; /* rows a thread looks at; 32 consecutive rows = 32 consecutive lanes */
-    int myLen[RPT], myBase[RPT], myDest[RPT];
+    int myLen[RPT], myDest[RPT];
+    unsigned myBase[RPT];
 #pragma unroll
     for (int j = 0; j < RPT; ++j) { /* round trip 1 */
         const int i = threadIdx.x + j * BLOCK;
@@ -79,9 +81,9 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
         if (live) {
             if constexpr (IS_HELL) {
                 const unsigned u0 = (unsigned)r, hs = (unsigned)a.hackSize;
-                myBase[j] = a.hackOffsets[u0 / hs] + (int)(u0 % hs);
+                myBase[j] = (unsigned)a.hackOffsets[u0 / hs] + u0 % hs;
             } else {
-                myBase[j] = (int)r;
+                myBase[j] = (unsigned)r;
             }
         }
     }
@@ -91,8 +93,8 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
         const int i = threadIdx.x + j * BLOCK;
         int first = 0, last = 0;
         if (XTILE && myLen[j] > 0) {
-            first = a.rP[myBase[j]];
-            last = a.rP[myBase[j] + (long long)(myLen[j] - 1) * a.idxStride];
+            first = a.rP[(long long)myBase[j]];
+            last = a.rP[(long long)myBase[j] + (long long)(myLen[j] - 1) * a.idxStride];
         }
         /* depth of the 32-row sub-group these 32 lanes hold; the deep ones register and are cut at deepCap */
         int depth = myLen[j];
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
         Pack<int, RPL> c[UNROLL];
     };
     auto loadItem = [&](int s, Item& it) {
-        it.slab = bases[s * LPC + sub];
+        it.slab = (long long)bases[s * LPC + sub];
         it.longest = 0;
 #pragma unroll
         for (int t = 0; t < RPL; ++t) {
@@ -391,9 +393,11 @@ static void launchRagged(hipStream_t stream, const SlabArgs<T>& a, int shape, bo
         return;
     }
     switch (shape) {
+#ifdef SPGPU_TUNING_VARIANTS
     case 1: SPGPU_RAGGED(8, 65536, 64); break;
     case 2: SPGPU_RAGGED(4, 49152, 32); break;
     case 3: SPGPU_RAGGED(4, 32768, 16); break;
+#endif
     default: SPGPU_RAGGED(8, 65536, 32); break;
     }
 #undef SPGPU_RAGGED

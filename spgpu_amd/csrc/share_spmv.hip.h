@@ -610,8 +610,10 @@ static void launchShare(hipStream_t stream, const SlabArgs<T>& a, int shape, boo
         return;
     }
     switch (shape) {
+#ifdef SPGPU_TUNING_VARIANTS
     case 1: SPGPU_SHARE(8, 57344, true, 64); break;
     case 2: SPGPU_SHARE(8, 49152, true, 32); break;
+#endif
     default: SPGPU_SHARE(8, 57344, true, 32); break;
     }
 #undef SPGPU_SHARE

@@ -12,6 +12,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     _ensure_built()
+    try:
+        config._lab_build = lab_build()
+    except Exception:  # noqa: BLE001 - no library: the tests that need it fail on their own
+        config._lab_build = False
 
 
 def _ensure_built():
@@ -25,6 +29,17 @@ def _ensure_built():
     missing = [target for target, path in need.items() if not os.path.exists(path)]
     if missing:
         subprocess.run(["make", "-C", ROOT, *missing], check=False)
+
+
+def lab_build():
+    """True if libspgpu.so carries the non-default kernel shapes (-DSPGPU_TUNING_VARIANTS, include/spgpu/tuning.h)."""
+    from spgpu_amd import capi
+    return bool(capi.spgpuTuningVariantsBuilt())
+
+
+# a test of a non-default kernel shape: runs on a library built with EXTRA_HIPFLAGS=-DSPGPU_TUNING_VARIANTS (the A/B tools'
+# build), skipped on the product build, which ignores the knobs that select those shapes
+lab = pytest.mark.skipif("not config._lab_build", reason="non-default kernel shape: needs a -DSPGPU_TUNING_VARIANTS build")
 
 
 @pytest.fixture(scope="session")

@@ -120,6 +120,7 @@ def tile_shape(letter, shape, deep=True):
     return O.slab_shape(letter, "xtile", shape, deep_cap=O.DEEP_CAP if deep else 0)
 
 
+@pytest.mark.skipif("not config._lab_build", reason="non-default kernel shape: -DSPGPU_TUNING_VARIANTS build")     # SPGPU_RAGGED=0: the deep split with fixed rows per wavefront
 @pytest.mark.parametrize("shape", [0, 1, 2, 3])
 @pytest.mark.parametrize("letter", ["S", "D"])
 @pytest.mark.parametrize("window,long_rows,pattern", [(512, 40, "near"), (0, 0, "near"), (1024, 0, "random")])
@@ -217,6 +218,7 @@ def test_one_column_matrix_strips_form(gpu):
     assert z.tobytes() == (v * 3.0).tobytes()
 
 
+@pytest.mark.skipif("not config._lab_build", reason="non-default kernel shape: -DSPGPU_TUNING_VARIANTS build")     # SPGPU_RAGGED=0
 @pytest.mark.parametrize("cap", [16, 128])
 @pytest.mark.parametrize("form", ["gather", "xtile"])
 @pytest.mark.parametrize("name", ["powerlaw_s_b1_h64", "powerlaw_d_b0_h32", "powerlaw_c_b0_h32", "powerlaw_z_b1_h64"])
@@ -264,7 +266,7 @@ def test_deep_queue_overflow_stays_correct(gpu, tuning):
         assert float((z - exact).abs().max()) <= 1e-12
 
 
-@pytest.mark.parametrize("shape,form", [(0, "auto"), (1, "auto"), (2, "auto"), (3, "auto"), (0, "gather")])
+@pytest.mark.parametrize("shape,form", [(0, "auto"), (0, "gather")] + [pytest.param(k, "auto", marks=pytest.mark.skipif("not config._lab_build", reason="non-default kernel shape: -DSPGPU_TUNING_VARIANTS build")) for k in (1, 2, 3)])
 @pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
 @pytest.mark.parametrize("window,long_rows,pattern,hack", [(512, 40, "near", 32), (0, 0, "near", 64), (1024, 0, "random", 32), (256, 100, "near", 96)])
 def test_ragged_kernel_through_ridx_bit_exact(gpu, tuning, letter, shape, form, window, long_rows, pattern, hack):

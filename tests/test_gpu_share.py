@@ -79,7 +79,10 @@ def _run_and_compare(gpu, letter, hell, r_idx, rng, form="auto", betas=((1.0, 0.
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
 
 
-@pytest.mark.parametrize("kernel,shape,form", [(KERNELS[0], 0, "auto"), (KERNELS[0], 1, "auto"), (KERNELS[0], 2, "auto"), (KERNELS[0], 0, "gather"),
+LAB = pytest.mark.skipif("not config._lab_build", reason="non-default kernel shape: -DSPGPU_TUNING_VARIANTS build")
+
+
+@pytest.mark.parametrize("kernel,shape,form", [(KERNELS[0], 0, "auto"), pytest.param(KERNELS[0], 1, "auto", marks=LAB), pytest.param(KERNELS[0], 2, "auto", marks=LAB), (KERNELS[0], 0, "gather"),
                                                (KERNELS[1], 0, "auto"), (KERNELS[1], 0, "gather"), (KERNELS[2], 0, "auto"), (KERNELS[2], 0, "gather")])
 @pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
 @pytest.mark.parametrize("hack", [32, 64, 96, 48, 2])

@@ -92,7 +92,8 @@ def test_fixture_parity_all_formats(gpu, name):
         assert z.tobytes() == O.hdia_spmv(hdia, g["x"], y, alpha, beta).tobytes()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 6, 12, 13, 17, 18, 21, 22])
+@pytest.mark.parametrize("variant", [0] + [pytest.param(v, marks=pytest.mark.skipif("not config._lab_build", reason="a forced kernel shape: -DSPGPU_TUNING_VARIANTS build"))
+                                           for v in (1, 2, 3, 4, 6, 12, 13, 17, 18, 21, 22)])
 @pytest.mark.parametrize("name", ["powerlaw_s_b1_h64", "powerlaw_d_b0_h32", "powerlaw_c_b0_h32", "powerlaw_z_b1_h64"])
 def test_every_kernel_variant_bit_exact(gpu, name, variant, tuning):
     from spgpu_amd import formats
@@ -101,7 +102,9 @@ def test_every_kernel_variant_bit_exact(gpu, name, variant, tuning):
     letter, ell, hell, _ = _mats(g)
     # Z (16-byte elements) has no wide form: wide requests run narrow 2x4 pipe
     rpl = 16 // np.dtype(O.NP_DTYPE[letter]).itemsize
-    if variant in (17, 18, 21, 22) and letter != "Z":
+    if variant == 0:          # what the library picks for the type (the only shapes of the product build)
+        want_of = lambda m, yy, b: O.default_spmv(m, g["x"], yy, g["alpha"][()], b)
+    elif variant in (17, 18, 21, 22) and letter != "Z":
         one_phase = variant in (17, 21)
         ph = 1 if one_phase else 2 * rpl                         # 18/22: wide kernel with 2*RPL phases x 2 columns
         shape = dict(group_rows=(64 // ph) * rpl, rows_per_lane=rpl, step=8 if one_phase else 2 * ph, tail_lanes=16, phases=ph)

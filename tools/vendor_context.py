@@ -8,7 +8,7 @@ import os
 
 _lib = None
 _handle = None
-OP_NONE = 0            # rocsparse_operation_none
+OP_NONE = 111          # rocsparse_operation_none
 INDEX_BASE_ZERO = 0
 
 
