@@ -75,7 +75,12 @@ void spgpuCommDestroy(void* comm);
 /* ---- the plan ------------------------------------------------------------------------------------------------- */
 /* blockFirstRow: world + 1 host entries.  rest may be NULL (or rows == 0) when the block has no foreign columns.
  * comm: the rank's ncclComm_t (any RCCL the process uses), NULL allowed for world == 1.
- * Collective over the communicator for SPGPU_EXCHANGE_NEEDED.  Synchronises the handle's stream. */
+ * Collective over the communicator for SPGPU_EXCHANGE_NEEDED: every rank must call it.  Synchronises the handle's stream.
+ * world <= 960 (SPGPU_UNSUPPORTED beyond).  Failure: the set-up's local steps (allocations, sorting) are followed by an
+ * agreement of all ranks before each of its collectives, so a failure on ONE rank makes EVERY rank return an error from
+ * this call instead of leaving the others inside a collective; if a send or receive of the row-number exchange cannot be
+ * posted, the communicator is aborted (ncclCommAbort, where the RCCL in use has it) rather than a half-posted group launched
+ * -- it must not be used again.  An error inside RCCL itself (a peer that died) is RCCL's to report. */
 spgpuStatus_t spgpuDhellspmmShardedCreate(spgpuShardedSpmm_t* plan, spgpuHandle_t handle, void* comm, int rank, int world,
                                           __host const long long* blockFirstRow, const spgpuHellBlockD* own,
                                           const spgpuHellBlockD* rest, int count, int exchange);

@@ -82,6 +82,7 @@ template <typename T> struct SlabArgs {
     T* deepItemSums;             /* [SPGPU_DEEP_ITEMS][32] */
     int xcdRun;                  /* raggedSpmvKernel: row blocks per XCD run (0: hardware order) */
     int pipeRanges;              /* pipeSpmvKernel: ranges per workgroup */
+    int avgNnzPerRow;            /* the caller's hint (0: none) */
 };
 
 constexpr int kBlockThreads = 256;
@@ -537,7 +538,9 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
             if (a.feedback) {
                 const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
                 if (group == sampleGroup(groups, 1) || group == sampleGroup(groups, 2) || group == sampleGroup(groups, 3)) {
-                    const int other = columnSpan() <= a.tileSpanLimit ? 3 : 1;
+                    /* rows that fit one stage: placing and filling an LDS tile costs two round trips more than the row's
+                     * one stage of gathers (1 M-row 5-point Laplacian: 25.9 us through the tile, 19.4 as gathers) */
+                    const int other = groupLongest > STEP && columnSpan() <= a.tileSpanLimit ? 3 : 1;
                     for (int q = 1; q <= 3; ++q)
                         if (group == sampleGroup(groups, q) && lane == 0)
                             /* at least half of it as strips -- and more than one stage of it: the test costs about a
@@ -898,7 +901,8 @@ __global__ __launch_bounds__(kWave) void formProbeKernel(const SlabArgs<T> a)
     const long long span = __ballot(below) != 0ull ? (1ll << 40) : (highest < lowest ? 0ll : (long long)highest - lowest + 1);
     const int asStrips = firstBad == 0x7fffffff ? groupLongest : firstBad / STEP * STEP; /* whole stages of strips in front */
     if (lane == 0 && a.feedback)
-        a.feedback[blockIdx.x] = (RPL > 1 && 2 * asStrips >= groupLongest && groupLongest > STEP) ? 2 : (span <= a.tileSpanLimit ? 3 : 1);
+        a.feedback[blockIdx.x] = (RPL > 1 && 2 * asStrips >= groupLongest && groupLongest > STEP) ? 2
+                                 : (groupLongest > STEP && span <= a.tileSpanLimit ? 3 : 1); /* one stage of rows: no tile */
 }
 
 /*
@@ -1099,6 +1103,18 @@ static void launchDeep(hipStream_t stream, const SlabArgs<T>& a)
     constexpr int UNROLL = 32 / PH; /* 32 columns per stage, two stages per item */
     hipLaunchKernelGGL((deepItemsKernel<T, RPL, IS_HELL, UNROLL, kDeepChunk>), dim3(2048), dim3(kBlockThreads), 0, stream, a);
     hipLaunchKernelGGL((deepFinishKernel<T>), dim3(256), dim3(kBlockThreads), 0, stream, a);
+}
+
+/* Short rows (see launchSlabFamily): a lane walks whole rows, 4 columns per stage, no prefetch; 8-byte element types. */
+template <typename T, int RPL, bool IS_HELL>
+static void launchLean(hipStream_t stream, const SlabArgs<T>& a)
+{
+    constexpr int GROUP_ROWS = kWave * RPL;
+    constexpr int WAVES = kBlockThreads / kWave;
+    const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
+    const unsigned blocks = (unsigned)((groups + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL((slabSpmvKernel<T, RPL, 1, IS_HELL, true, 4, 0, true, 0, false, kBlockThreads, 0, false, 1, 8>), dim3(blocks),
+                       dim3(kBlockThreads), 0, stream, a);
 }
 
 /* The probe of the type's default kernel shape (launchSlabFamily): D/C walk whole rows, 8 columns per stage; S 8 phases x 2. */
@@ -1324,7 +1340,16 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             default: /* 21 */
                 if (tiled || autoTile)
                     launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
-                else if (strips)
+                else if (a.avgNnzPerRow > 0 && a.avgNnzPerRow <= 8 && form == SPGPU_SPMV_FORM_AUTO) {
+                    /* the caller says the rows are short (avgNnzPerRow: the reference's own tuning hint, which picks its
+                     * threads-per-row shape, hell_spmv_base_template.cuh:306-325): such a row is one stage, and a kernel
+                     * without the prefetch ring needs a third of the registers -- all wavefronts of a 1 M-row system are
+                     * resident at once instead of queueing in three rounds (19.4 -> 17.4 us on configs[0]).  Same order of
+                     * additions (the tail switch is considered every 8 columns, as in the default kernel). */
+                    spgpuNoteSpmvForm(handle, SPGPU_SPMV_FORM_GATHER);
+                    a.feedback = nullptr;
+                    launchLean<T, WIDE, IS_HELL>(stream, a);
+                } else if (strips)
                     launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true, 0, true>(stream, a, nt);
                 else
                     launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true>(stream, a, nt);
@@ -1354,7 +1379,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
 template <typename T, typename ApiT>
 static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, const ApiT* cM, const int* rP,
                      int hackSize, const int* hackOffsets, const int* rS, const int* rIdx, int rows,
-                     const ApiT* x, ApiT beta, int baseIndex)
+                     const ApiT* x, ApiT beta, int baseIndex, int avgNnzPerRow = 0)
 {
     static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
     SlabArgs<T> a;
@@ -1375,6 +1400,7 @@ static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     a.valStride = hackSize;
     a.idxStride = hackSize;
     a.wideIO = 0;
+    a.avgNnzPerRow = avgNnzPerRow;
     launchSlabFamily<T, true>(handle, a);
     spgpuDebugCheck(handle, "hellspmv");
 }
@@ -1382,7 +1408,7 @@ static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
 template <typename T, typename ApiT>
 static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, const ApiT* cM, const int* rP,
                     int cMPitch, int rPPitch, const int* rS, const int* rIdx, int maxNnzPerRow, int rows,
-                    const ApiT* x, ApiT beta, int baseIndex)
+                    const ApiT* x, ApiT beta, int baseIndex, int avgNnzPerRow = 0)
 {
     static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
     SlabArgs<T> a;
@@ -1403,6 +1429,7 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
     a.valStride = cMPitch;
     a.idxStride = rPPitch;
     a.wideIO = 0;
+    a.avgNnzPerRow = avgNnzPerRow;
     launchSlabFamily<T, false>(handle, a);
     spgpuDebugCheck(handle, "ellspmv");
 }
@@ -1546,23 +1573,21 @@ void spgpuDebugCheck(spgpuHandle_t h, const char* what)
 #endif
 }
 
-/* avgNnzPerRow is a tuning hint in the reference (threads-per-row choice,
- * hell_spmv_base_template.cuh:306-325); the slab kernel does not need it. */
+/* avgNnzPerRow is a tuning hint in the reference (threads-per-row choice, hell_spmv_base_template.cuh:306-325); here it
+ * selects the kernel without a prefetch ring when it says 1 .. 8 (launchSlabFamily); any value gives the same bits. */
 
 void spgpuShellspmv(spgpuHandle_t handle, float* z, const float* y, float alpha, const float* cM,
                     const int* rP, int hackSize, const int* hackOffsets, const int* rS, const int* rIdx,
                     int avgNnzPerRow, int rows, const float* x, float beta, int baseIndex)
 {
-    (void)avgNnzPerRow;
-    hellSpmv<float>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex);
+    hellSpmv<float>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex, avgNnzPerRow);
 }
 
 void spgpuDhellspmv(spgpuHandle_t handle, double* z, const double* y, double alpha, const double* cM,
                     const int* rP, int hackSize, const int* hackOffsets, const int* rS, const int* rIdx,
                     int avgNnzPerRow, int rows, const double* x, double beta, int baseIndex)
 {
-    (void)avgNnzPerRow;
-    hellSpmv<double>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex);
+    hellSpmv<double>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex, avgNnzPerRow);
 }
 
 void spgpuChellspmv(spgpuHandle_t handle, hipFloatComplex* z, const hipFloatComplex* y, hipFloatComplex alpha,
@@ -1570,8 +1595,7 @@ void spgpuChellspmv(spgpuHandle_t handle, hipFloatComplex* z, const hipFloatComp
                     const int* rS, const int* rIdx, int avgNnzPerRow, int rows, const hipFloatComplex* x,
                     hipFloatComplex beta, int baseIndex)
 {
-    (void)avgNnzPerRow;
-    hellSpmv<cfloat>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex);
+    hellSpmv<cfloat>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex, avgNnzPerRow);
 }
 
 void spgpuZhellspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleComplex* y,
@@ -1579,26 +1603,21 @@ void spgpuZhellspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleCo
                     const int* hackOffsets, const int* rS, const int* rIdx, int avgNnzPerRow, int rows,
                     const hipDoubleComplex* x, hipDoubleComplex beta, int baseIndex)
 {
-    (void)avgNnzPerRow;
-    hellSpmv<cdouble>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex);
+    hellSpmv<cdouble>(handle, z, y, alpha, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, x, beta, baseIndex, avgNnzPerRow);
 }
 
 void spgpuSellspmv(spgpuHandle_t handle, float* z, const float* y, float alpha, const float* cM, const int* rP,
                    int cMPitch, int rPPitch, const int* rS, const int* rIdx, int avgNnzPerRow,
                    int maxNnzPerRow, int rows, const float* x, float beta, int baseIndex)
 {
-    (void)avgNnzPerRow;
-    ellSpmv<float>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
-                   baseIndex);
+    ellSpmv<float>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta, baseIndex, avgNnzPerRow);
 }
 
 void spgpuDellspmv(spgpuHandle_t handle, double* z, const double* y, double alpha, const double* cM,
                    const int* rP, int cMPitch, int rPPitch, const int* rS, const int* rIdx, int avgNnzPerRow,
                    int maxNnzPerRow, int rows, const double* x, double beta, int baseIndex)
 {
-    (void)avgNnzPerRow;
-    ellSpmv<double>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
-                    baseIndex);
+    ellSpmv<double>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta, baseIndex, avgNnzPerRow);
 }
 
 void spgpuCellspmv(spgpuHandle_t handle, hipFloatComplex* z, const hipFloatComplex* y, hipFloatComplex alpha,
@@ -1606,9 +1625,7 @@ void spgpuCellspmv(spgpuHandle_t handle, hipFloatComplex* z, const hipFloatCompl
                    const int* rIdx, int avgNnzPerRow, int maxNnzPerRow, int rows, const hipFloatComplex* x,
                    hipFloatComplex beta, int baseIndex)
 {
-    (void)avgNnzPerRow;
-    ellSpmv<cfloat>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
-                    baseIndex);
+    ellSpmv<cfloat>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta, baseIndex, avgNnzPerRow);
 }
 
 void spgpuZellspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleComplex* y, hipDoubleComplex alpha,
@@ -1616,9 +1633,7 @@ void spgpuZellspmv(spgpuHandle_t handle, hipDoubleComplex* z, const hipDoubleCom
                    const int* rIdx, int avgNnzPerRow, int maxNnzPerRow, int rows, const hipDoubleComplex* x,
                    hipDoubleComplex beta, int baseIndex)
 {
-    (void)avgNnzPerRow;
-    ellSpmv<cdouble>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta,
-                     baseIndex);
+    ellSpmv<cdouble>(handle, z, y, alpha, cM, rP, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, x, beta, baseIndex, avgNnzPerRow);
 }
 
 /* alpha is accepted and not applied, as in the reference (ell_csput_base.cuh:35,44,66). */

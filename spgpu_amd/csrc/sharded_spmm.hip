@@ -37,6 +37,7 @@ struct Rccl {
     ncclResult_t (*recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*groupStart)(void);
     ncclResult_t (*groupEnd)(void);
+    ncclResult_t (*commAbort)(ncclComm_t); /* optional */
     const char* (*errorString)(ncclResult_t);
 };
 static Rccl rccl;
@@ -74,6 +75,7 @@ static bool loadRccl()
             SPGPU_RCCL_SYM(recv, "ncclRecv");
             SPGPU_RCCL_SYM(groupStart, "ncclGroupStart");
             SPGPU_RCCL_SYM(groupEnd, "ncclGroupEnd");
+            SPGPU_RCCL_SYM(commAbort, "ncclCommAbort");
             SPGPU_RCCL_SYM(errorString, "ncclGetErrorString");
 #undef SPGPU_RCCL_SYM
             if (rccl.getUniqueId && rccl.commInitRank && rccl.commInitAll && rccl.commDestroy && rccl.allGather && rccl.send &&
@@ -236,6 +238,30 @@ static void freePlan(spgpuShardedSpmm_t p)
     free(p);
 }
 
+/* Do ALL ranks say yes?  One ncclAllGather of a status word through the handle's reduction scratch (allocated in
+ * spgpuCreate: no allocation here that could fail on one rank only).  Every rank of the communicator must call this at the same
+ * point of the set-up, whatever happened to it locally before: a rank that left the set-up on a local failure (hipMalloc,
+ * rocPRIM, host malloc) without saying so would leave its peers inside the next collective for ever. */
+static bool everyRankOk(spgpuShardedSpmm_t p, bool mine)
+{
+    if (p->world == 1)
+        return mine;
+    hipStream_t s = p->handle->currentStream;
+    int* word = (int*)spgpuPrivate(p->handle)->reduceScratch; /* [0]: mine, [64 ...]: everyone's (world <= 1024) */
+    int* all = word + 64;
+    int host[1024];
+    const int flag = mine ? 1 : 0;
+    if (!hipOk(hipMemcpyAsync(word, &flag, sizeof(int), hipMemcpyHostToDevice, s), "copy") ||
+        !rcclOk(rccl.allGather(word, all, 1, ncclInt32, p->comm, s), "ncclAllGather(status)") ||
+        !hipOk(hipMemcpyAsync(host, all, (size_t)p->world * sizeof(int), hipMemcpyDeviceToHost, s), "copy") ||
+        !hipOk(hipStreamSynchronize(s), "sync"))
+        return false;
+    bool ok = true;
+    for (int r = 0; r < p->world; ++r)
+        ok = ok && host[r] == 1;
+    return ok;
+}
+
 /* the needed-rows set-up; collective over the communicator */
 static spgpuStatus_t setUpNeeded(spgpuShardedSpmm_t p)
 {
@@ -251,7 +277,12 @@ static spgpuStatus_t setUpNeeded(spgpuShardedSpmm_t p)
     spgpuStatus_t status = SPGPU_UNSPECIFIED;
     long long count = 0;
 
-    do {
+    int* hostWant = nullptr;
+    int* hostAll = nullptr;
+    /* The set-up is a sequence of LOCAL phases (allocations, rocPRIM, kernels, host memory), each closed by an agreement of
+     * all ranks (everyRankOk) before the collective that follows: either every rank enters that collective or none does. */
+    bool local = false;
+    do { /* phase 1 (local): the distinct off-block columns, cut at the row-block boundaries, rest renumbered */
         if (!hipOk(hipMalloc(&dBounds, (world + 1) * sizeof(long long)), "hipMalloc") ||
             !hipOk(hipMalloc(&dFirst, (world + 1) * sizeof(long long)), "hipMalloc") ||
             !hipOk(hipMemcpyAsync(dFirst, p->blockFirst, (world + 1) * sizeof(long long), hipMemcpyHostToDevice, s), "copy"))
@@ -284,66 +315,69 @@ static spgpuStatus_t setUpNeeded(spgpuShardedSpmm_t p)
                 break;
             count = (long long)distinct;
         }
-        /* cut the list at the row-block boundaries; what lies behind the last boundary is padding, not a row */
-        hipLaunchKernelGGL(ownerBoundsKernel, dim3(1), dim3(world + 1 <= 1024 ? world + 1 : 1024), 0, s, dBounds, needed, count, dFirst,
-                           world);
-        if (world + 1 > 1024)
-            break;
+        /* cut the list at the row-block boundaries; what lies behind the last boundary is padding, not a row
+         * (world + 1 <= 1024 lanes: spgpuDhellspmmShardedCreate refuses larger communicators) */
+        hipLaunchKernelGGL(ownerBoundsKernel, dim3(1), dim3(world + 1), 0, s, dBounds, needed, count, dFirst, world);
         if (!hipOk(hipMemcpyAsync(p->want, dBounds, (world + 1) * sizeof(long long), hipMemcpyDeviceToHost, s), "copy") ||
             !hipOk(hipStreamSynchronize(s), "sync"))
             break;
         p->neededRows = p->want[world];
-
         if (slots > 0) {
             if (!hipOk(hipMalloc(&p->restRP, slots * sizeof(int)), "hipMalloc"))
                 break;
             hipLaunchKernelGGL(renumberKernel, dim3(gridOverSh(slots)), dim3(kShThreads), 0, s, p->restRP, p->rest.rP, slots,
                                p->rest.baseIndex, needed, p->neededRows);
         }
-
-        /* who wants how many of my rows: all-gather of every rank's per-owner counts */
-        int* hostWant = (int*)malloc((size_t)world * sizeof(int));
-        int* hostAll = (int*)malloc((size_t)world * world * sizeof(int));
+        hostWant = (int*)malloc((size_t)world * sizeof(int));
+        hostAll = (int*)malloc((size_t)world * world * sizeof(int));
         if (!hostWant || !hostAll) {
-            free(hostWant);
-            free(hostAll);
             status = SPGPU_OUTOFMEMORY;
             break;
         }
         for (int r = 0; r < world; ++r)
             hostWant[r] = (int)(p->want[r + 1] - p->want[r]);
-        bool ok = true;
+        if (world > 1 && (!hipOk(hipMalloc(&dWant, world * sizeof(int)), "hipMalloc") ||
+                          !hipOk(hipMalloc(&dAllWant, (size_t)world * world * sizeof(int)), "hipMalloc") ||
+                          !hipOk(hipMemcpyAsync(dWant, hostWant, world * sizeof(int), hipMemcpyHostToDevice, s), "copy")))
+            break;
+        /* tests: SPGPU_TEST_FAIL_SETUP_RANK = r makes rank r's local phase fail here (tests/test_gpu_sharded_c.py) */
+        const char* failing = getenv("SPGPU_TEST_FAIL_SETUP_RANK");
+        local = !(failing && failing[0] && atoi(failing) == p->rank);
+    } while (0);
+
+    do {
+        if (!everyRankOk(p, local))
+            break;
+        /* who wants how many of my rows: all-gather of every rank's per-owner counts */
         if (world > 1) {
-            ok = hipOk(hipMalloc(&dWant, world * sizeof(int)), "hipMalloc") && hipOk(hipMalloc(&dAllWant, (size_t)world * world * sizeof(int)), "hipMalloc") &&
-                 hipOk(hipMemcpyAsync(dWant, hostWant, world * sizeof(int), hipMemcpyHostToDevice, s), "copy") &&
-                 rcclOk(rccl.allGather(dWant, dAllWant, (size_t)world, ncclInt32, p->comm, s), "ncclAllGather(counts)") &&
-                 hipOk(hipMemcpyAsync(hostAll, dAllWant, (size_t)world * world * sizeof(int), hipMemcpyDeviceToHost, s), "copy") &&
-                 hipOk(hipStreamSynchronize(s), "sync");
+            if (!rcclOk(rccl.allGather(dWant, dAllWant, (size_t)world, ncclInt32, p->comm, s), "ncclAllGather(counts)") ||
+                !hipOk(hipMemcpyAsync(hostAll, dAllWant, (size_t)world * world * sizeof(int), hipMemcpyDeviceToHost, s), "copy") ||
+                !hipOk(hipStreamSynchronize(s), "sync"))
+                break;
         } else {
             hostAll[0] = hostWant[0];
         }
-        if (ok) {
-            p->give[0] = 0;
-            for (int r = 0; r < world; ++r)
-                p->give[r + 1] = p->give[r] + hostAll[(size_t)r * world + p->rank];
-        }
-        free(hostWant);
-        free(hostAll);
-        if (!ok)
-            break;
+        p->give[0] = 0;
+        for (int r = 0; r < world; ++r)
+            p->give[r + 1] = p->give[r] + hostAll[(size_t)r * world + p->rank];
 
-        /* the row numbers themselves: every rank tells every owner which of its rows it wants */
+        /* phase 2 (local): the row numbers this rank asks for, room for the ones it is asked for */
         const long long sendRows = p->give[world];
+        local = true;
         if (p->neededRows > 0) {
-            if (!hipOk(hipMalloc(&ask, p->neededRows * sizeof(int)), "hipMalloc"))
-                break;
-            hipLaunchKernelGGL(askKernel, dim3(gridOverSh(p->neededRows)), dim3(kShThreads), 0, s, ask, needed, p->neededRows, dBounds,
-                               dFirst, world);
+            local = hipOk(hipMalloc(&ask, p->neededRows * sizeof(int)), "hipMalloc");
+            if (local)
+                hipLaunchKernelGGL(askKernel, dim3(gridOverSh(p->neededRows)), dim3(kShThreads), 0, s, ask, needed, p->neededRows, dBounds,
+                                   dFirst, world);
         }
-        if (sendRows > 0 && !hipOk(hipMalloc(&p->sendIndex, sendRows * sizeof(int)), "hipMalloc"))
+        if (local && sendRows > 0)
+            local = hipOk(hipMalloc(&p->sendIndex, sendRows * sizeof(int)), "hipMalloc");
+        if (!everyRankOk(p, local))
             break;
+        /* every rank tells every owner which of its rows it wants */
         if (world > 1 && !rcclOk(rccl.groupStart(), "ncclGroupStart"))
             break;
+        bool ok = true;
         for (int r = 0; r < world && ok; ++r) {
             const long long wantRows = p->want[r + 1] - p->want[r], giveRows = p->give[r + 1] - p->give[r];
             if (r == p->rank) {
@@ -357,18 +391,31 @@ static spgpuStatus_t setUpNeeded(spgpuShardedSpmm_t p)
             if (giveRows > 0)
                 ok = ok && rcclOk(rccl.recv(p->sendIndex + p->give[r], (size_t)giveRows, ncclInt32, r, p->comm, s), "ncclRecv(rows)");
         }
+        if (world > 1 && !ok && rccl.commAbort) {
+            /* a half-posted group must not be launched: the communicator is given up instead (its peers' calls then fail
+             * rather than wait); the caller must not use it again */
+            (void)rccl.commAbort(p->comm);
+            p->comm = nullptr;
+            break;
+        }
         if (world > 1 && !rcclOk(rccl.groupEnd(), "ncclGroupEnd"))
             break;
         if (!ok || !hipOk(hipStreamSynchronize(s), "sync"))
             break;
 
+        /* phase 3 (local): the exchange buffers; the ranks agree once more so that all return the same status */
         const size_t rowBytes = (size_t)p->count * sizeof(double);
-        if (p->neededRows > 0 && !hipOk(hipMalloc(&p->xNeeded, p->neededRows * rowBytes), "hipMalloc"))
-            break;
-        if (sendRows > 0 && !hipOk(hipMalloc(&p->sendBuffer, sendRows * rowBytes), "hipMalloc"))
+        local = true;
+        if (p->neededRows > 0)
+            local = hipOk(hipMalloc(&p->xNeeded, p->neededRows * rowBytes), "hipMalloc");
+        if (local && sendRows > 0)
+            local = hipOk(hipMalloc(&p->sendBuffer, sendRows * rowBytes), "hipMalloc");
+        if (!everyRankOk(p, local))
             break;
         status = SPGPU_SUCCESS;
     } while (0);
+    free(hostWant);
+    free(hostAll);
 
     (void)hipStreamSynchronize(s);
     (void)hipFree(keys);
@@ -437,6 +484,8 @@ spgpuStatus_t spgpuDhellspmmShardedCreate(spgpuShardedSpmm_t* plan, spgpuHandle_
     if (!handle || !blockFirstRow || !own || world < 1 || rank < 0 || rank >= world || count <= 0 ||
         (exchange != SPGPU_EXCHANGE_ALLGATHER && exchange != SPGPU_EXCHANGE_NEEDED))
         return SPGPU_UNSPECIFIED;
+    if (world > 960) /* the set-up cuts the needed rows with one lane per rank and agrees through 4 KiB of status words */
+        return SPGPU_UNSUPPORTED;
     if (world > 1 && (!comm || !loadRccl()))
         return SPGPU_UNSUPPORTED;
     for (int r = 0; r < world; ++r)

@@ -53,6 +53,12 @@ def rank_main(rank):
         plan = capi.ShardedPlan()
         kind = capi.EXCHANGE_NEEDED if exchange == "needed" else capi.EXCHANGE_ALLGATHER
         status = capi.spgpuDhellspmmShardedCreate(C.byref(plan), handle, comm, rank, world, firsts, C.byref(ob), C.byref(rb), k, kind)
+        if os.environ.get("SPGPU_TEST_FAIL_SETUP_RANK"):
+            # one rank's local set-up is made to fail: EVERY rank must come back from Create with an error (none may hang)
+            results[rank] = (status != capi.SPGPU_SUCCESS, f"rank {rank}: Create returned {status} (a peer's set-up failed)")
+            capi.spgpuCommDestroy(comm)
+            capi.spgpuDestroy(handle)
+            return
         assert status == capi.SPGPU_SUCCESS, f"Create returned {status}"
         hold = synth.hell_rows_to_host(block, 0, rows)
         ys = y.cpu().numpy()

@@ -174,3 +174,17 @@ def test_many_ranks_as_threads(mock_rccl, world, pattern, exchange, shape):
     run = subprocess.run([sys.executable, os.path.join(here, "run_sharded_ranks.py"), str(world), pattern, exchange, shape],
                          capture_output=True, text=True, timeout=600, env=env)
     assert run.returncode == 0 and "ALL RANKS OK" in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]
+
+
+def test_a_rank_that_fails_its_set_up_takes_every_rank_out_together(gpu, mock_rccl):
+    """The needed-rows set-up is collective.  One of three ranks fails a LOCAL step (injected: SPGPU_TEST_FAIL_SETUP_RANK);
+    the ranks agree before every collective, so all three come back from spgpuDhellspmmShardedCreate with an error and
+    none is left waiting inside RCCL (the helper reports ranks that did not finish)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SPGPU_RCCL_LIBRARY=mock_rccl, SPGPU_TEST_FAIL_SETUP_RANK="1")
+    run = subprocess.run([sys.executable, os.path.join(here, "run_sharded_ranks.py"), "3", "window", "needed", "uneven"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0 and "ALL RANKS OK" in run.stdout and "did not finish" not in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]
+    assert run.stdout.count("a peer's set-up failed") == 3
