@@ -906,6 +906,47 @@ __global__ __launch_bounds__(kWave) void formProbeKernel(const SlabArgs<T> a)
 }
 
 /*
+ * Rows with a row order (rIdx): how far from the diagonal -- in the ORIGINAL numbering, rIdx[row] -- do their columns lie?
+ * The queue kernel for ordered rows has two product shapes (ragged_spmv.hip.h, launchRagged): 2 048 rows per workgroup with
+ * the results staged in LDS by destination (whole-line stores of z; 48 KiB left for the x tile) wins when the columns of a
+ * window of rows fit that tile, 1 024 rows with a 64 KiB tile when they spread further (columns +-2 048 of the row: 2 048
+ * rows would need 64 KiB and more).  192 sampled rows answer: 4 = three quarters of them keep within 1 024 of the
+ * diagonal, 5 = they do not.  Launched by AUTO when it has no answer for the matrix, and again every 64th call.
+ */
+template <bool IS_HELL>
+__global__ __launch_bounds__(kWave) void orderedProbeKernel(const int* rP, const int* rS, const int* hackOffsets, const int* rIdx, int hackSize,
+                                                           long long idxStride, int maxNnz, int rows, int baseIndex, int* answer)
+{
+    const int lane = threadIdx.x;
+    int near = 0, seen = 0;
+    for (int q = 1; q <= 3; ++q) {
+        const long long r = (long long)rows * q / 4 + 2 * q + lane;
+        if (r >= rows)
+            continue;
+        const int len = rS ? rS[r] : maxNnz;
+        if (len <= 0)
+            continue;
+        long long slot;
+        if constexpr (IS_HELL)
+            slot = (long long)hackOffsets[(unsigned)r / (unsigned)hackSize] + (unsigned)r % (unsigned)hackSize;
+        else
+            slot = r;
+        const long long dest = rIdx[r];
+        const long long first = (long long)rP[slot] - baseIndex - dest, last = (long long)rP[slot + (long long)(len - 1) * idxStride] - baseIndex - dest;
+        const long long reach = (first < 0 ? -first : first) > (last < 0 ? -last : last) ? (first < 0 ? -first : first) : (last < 0 ? -last : last);
+        seen += 1;
+        near += reach <= 1024 ? 1 : 0;
+    }
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+        near += laneXor(near, m);
+        seen += laneXor(seen, m);
+    }
+    if (lane == 0)
+        *answer = (seen > 0 && 4 * near >= 3 * seen) ? 4 : 5;
+}
+
+/*
  * SWEEP form (include/spgpu/tuning.h; chosen by the caller, never by AUTO): for matrices whose columns are scattered over
  * all of x but ascend inside a row.  A lane owns PACKS packs of VEC neighbouring rows (32 rows for 4- and 8-byte elements)
  * and carries all of them through the slab columns in step; the grid is small enough to be resident at once and walks
@@ -1256,8 +1297,20 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         a.wideIO = 0;
         a.feedback = nullptr;
         spgpuNoteSpmvForm(handle, form != SPGPU_SPMV_FORM_GATHER ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
-        launchRagged<T, WIDE, IS_HELL, true>(stream, a, tune->raggedShape, form != SPGPU_SPMV_FORM_GATHER);
-        if (deepPossible)
+        int shape = tune->raggedShape;
+        if (shape == 0 && form != SPGPU_SPMV_FORM_GATHER && a.rIdx != nullptr && sizeof(T) <= 8) {
+            /* which of the two product shapes?  (orderedProbeKernel; the answer is kept with AUTO's per-matrix words and
+             * read without synchronisation: a first call runs the 1 024-row shape, which is never far off) */
+            int calls = 0;
+            int* seen = spgpuFormFeedback(handle, a.rP, a.rows, &calls);
+            const int said = ((volatile int*)seen)[3];
+            if (said == 0 || calls % 64 == 0)
+                hipLaunchKernelGGL((orderedProbeKernel<IS_HELL>), dim3(1), dim3(kWave), 0, stream, a.rP, a.rS, a.hackOffsets, a.rIdx, a.hackSize,
+                                   a.idxStride, a.maxNnz, a.rows, a.baseIndex, seen + 3);
+            shape = said == 4 ? 4 : 0;
+        }
+        const bool deepKernels = launchRagged<T, WIDE, IS_HELL, true>(stream, a, shape, form != SPGPU_SPMV_FORM_GATHER);
+        if (deepPossible && deepKernels)
             launchDeep<T, WIDE, IS_HELL>(stream, a);
         return;
     }

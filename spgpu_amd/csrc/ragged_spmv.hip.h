@@ -24,8 +24,9 @@
  * Algorithmic bytes as for slabSpmvKernel, plus 4 per row for rIdx.
  */
 
-template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int TILE_BYTES, int SUBS, bool DEEP>
-__global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs<T> a)
+template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int TILE_BYTES, int SUBS, bool DEEP, int ZBYTES = 0>
+__global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4)))
+void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavefront workgroups per CU (what LDS admits) */
 {
     constexpr int LPC = 32 / RPL;   /* lanes per slab column of a sub-group */
     constexpr int PH = kWave / LPC; /* slab columns per wave-wide load */
@@ -34,12 +35,27 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
     constexpr int ROWS = SUBS * 32;
     constexpr bool XTILE = TILE_BYTES > 0;
     constexpr int TILE_ELEMS = XTILE ? TILE_BYTES / (int)sizeof(T) : 1;
+    /* ZSTAGE: the workgroup's results wait in LDS, placed by destination, and leave in whole lines when its queue is empty.
+     * The L2 does not merge stores over time (every store's bytes leave it at once): written from the lanes that hold the
+     * sums, z[rIdx[r]] is one 8-byte fabric write per row -- 3 % of the kernel's time with the rows ordered in windows of
+     * 1 024, 6 % at 2 048, 12 % at 4 096 (profiles/r03_exp_z_scatter.txt).  ZW destinations from the workgroup's lowest. */
+    constexpr bool ZSTAGE = ZBYTES > 0;
+    constexpr int ZW = ZSTAGE ? ZBYTES / (int)sizeof(T) : 32;
+    static_assert(ZW < 0xFFFF && ZW % 32 == 0, "a staged destination is a 16-bit offset");
     static_assert(SUBS >= WAVES, "every wavefront starts with a sub-group of its own");
 
     __shared__ __attribute__((aligned(16))) T tile[TILE_ELEMS];
-    __shared__ int lens[ROWS];        /* row lengths as walked here (deep sub-groups: cut at deepCap) */
-    __shared__ int dests[ROWS];       /* rIdx of the workgroup's rows: fetched from global memory at the end of a sub-group it would be
-                                         waited for with vmcnt(0) -- counters retire in order -- and drain the wavefront's prefetch */
+    /* row lengths as walked here (deep sub-groups: cut at deepCap); 16 bits each, 0xFFFF = "65 535 or more: ask rS" (a
+     * row that long is walked whole only when the deep list was full) */
+    __shared__ unsigned short lens[ROWS];
+    /* rIdx of the workgroup's rows (fetched from global memory at the end of a sub-group it would be waited for with vmcnt(0)
+     * -- counters retire in order -- and drain the wavefront's prefetch); ZSTAGE: as offsets from the workgroup's lowest
+     * destination instead, 0xFFFF = beyond the staging buffer */
+    __shared__ int dests[ZSTAGE ? 1 : ROWS];
+    __shared__ unsigned short destOffset[ZSTAGE ? ROWS : 1];
+    __shared__ __attribute__((aligned(16))) T staged[ZW];
+    __shared__ unsigned stagedMask[ZW / 32];
+    __shared__ int lowestDest;
     __shared__ unsigned bases[ROWS / RPL]; /* first slot of every RPL-row strip, in elements (hackOffsets is an int array: a slot
                                               number plus the offset inside the hack fits 32 unsigned bits; 64-bit from here on) */
     __shared__ int depths[SUBS];      /* longest walked row of every sub-group */
@@ -87,6 +103,12 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
             }
         }
     }
+    if constexpr (ZSTAGE) {
+        if (threadIdx.x < ZW / 32)
+            stagedMask[threadIdx.x] = 0u;
+        if (threadIdx.x == 0)
+            lowestDest = 0x7fffffff;
+    }
     ColumnProbe mine{0x7fffffff, -0x7fffffff - 1, 0, 0};
 #pragma unroll
     for (int j = 0; j < RPT; ++j) { /* round trip 2 */
@@ -110,8 +132,10 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
             slot = __shfl(slot, lane & 32, kWave);
         }
         if (i < ROWS) {
-            lens[i] = (slot >= 0 && myLen[j] > a.deepCap) ? a.deepCap : myLen[j];
-            dests[i] = myDest[j];
+            const int walked = (slot >= 0 && myLen[j] > a.deepCap) ? a.deepCap : myLen[j];
+            lens[i] = (unsigned short)(walked < 0xFFFF ? walked : 0xFFFF);
+            if constexpr (!ZSTAGE)
+                dests[i] = myDest[j];
             if (i % RPL == 0)
                 bases[i / RPL] = myBase[j];
             if ((lane & 31) == 0) {
@@ -143,7 +167,37 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
     }
     if (threadIdx.x == 0)
         nextItem = WAVES; /* the first WAVES sub-groups are dealt out statically */
+    if constexpr (ZSTAGE) {
+        __syncthreads(); /* lowestDest and stagedMask initialised */
+        int low = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int i = threadIdx.x + j * BLOCK;
+            if (i < ROWS && blockRow0 + i < a.rows)
+                low = myDest[j] < low ? myDest[j] : low;
+        }
+        low = waveMin(low);
+        if (lane == 0)
+            atomicMin(&lowestDest, low);
+    }
     __syncthreads();
+    int zBase = 0;
+    if constexpr (ZSTAGE) {
+        zBase = lowestDest;
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int i = threadIdx.x + j * BLOCK;
+            if (i < ROWS) {
+                const long long off = (long long)myDest[j] - zBase;
+                /* (rows of a deep sub-group are finished by the deep kernels: nothing of theirs is staged) */
+                const bool in = blockRow0 + i < a.rows && off >= 0 && off < ZW && !(DEEP && deepSlots[i >> 5] >= 0);
+                destOffset[i] = in ? (unsigned short)off : (unsigned short)0xFFFF;
+                if (in)
+                    atomicOr(&stagedMask[off >> 5], 1u << (off & 31));
+            }
+        }
+        /* (read by the wavefronts at the end of their first sub-group at the earliest: the tile's barrier lies between) */
+    }
 
     /* ---- the per-sub-group state of a lane, and the stage loads --------------------------------------------------- */
     struct Item {
@@ -162,6 +216,10 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
 #pragma unroll
         for (int t = 0; t < RPL; ++t) {
             it.len[t] = lens[s * 32 + sub * RPL + t];
+            if (it.len[t] == 0xFFFF) { /* see lens: not cut (the sub-group has no deep slot), so the row's own length */
+                const long long r = blockRow0 + s * 32 + sub * RPL + t;
+                it.len[t] = a.rS ? a.rS[r] : a.maxNnz;
+            }
             it.longest = it.len[t] > it.longest ? it.len[t] : it.longest;
         }
         it.depth = depths[s];
@@ -348,6 +406,15 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
                     if (r < a.rows) {
                         if (DEEP && deepSlot >= 0) {
                             a.deepPartials[(size_t)deepSlot * 32 + (size_t)(sub * RPL + t)] = sum[t];
+                        } else if constexpr (ZSTAGE) {
+                            const unsigned off = destOffset[s * 32 + sub * RPL + t];
+                            if (off != 0xFFFFu) {
+                                staged[off] = mul(a.alpha, sum[t]); /* beta * y joins when the line is written */
+                            } else { /* beyond the staging buffer: the scattered store, its destination from global memory */
+                                const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+                                a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
+                                                      : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
+                            }
                         } else {
                             const int outRow = dests[s * 32 + sub * RPL + t];
                             a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
@@ -370,6 +437,16 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
         if (ring[2].s >= SUBS) break;
         step(ring[2], ring[1]);
     }
+    if constexpr (ZSTAGE) {
+        __syncthreads(); /* every staged sum is in LDS */
+        for (int e = threadIdx.x; e < ZW; e += BLOCK) {
+            if ((stagedMask[e >> 5] >> (e & 31)) & 1u) { /* consecutive lanes, consecutive destinations: whole lines where the workgroup holds them */
+                const long long outRow = (long long)zBase + e;
+                const T v = staged[e];
+                a.z[outRow] = hasBeta ? mulAdd(a.beta, a.y[outRow], v) : v;
+            }
+        }
+    }
 #ifdef SPGPU_TRACE_BLOCKS
     if (spgpuTraceBuffer && lane == 0)
         atomicMax(&spgpuTraceBuffer[3 * (size_t)blockIdx.x + 1], (unsigned long long)wall_clock64());
@@ -380,17 +457,21 @@ __global__ __launch_bounds__(WAVES * kWave) void raggedSpmvKernel(const SlabArgs
 #define SPGPU_RAGGED_UNROLL(RPL) ((RPL) >= 4 ? 2 : 3) /* wave-wide loads per stage; 3 keeps the 8-byte kernels at 112 VGPRs (4 wavefronts per SIMD: two 8-wavefront workgroups per CU) with two stages in flight */
 #endif
 /* Shapes (SPGPU_RAGGED_SHAPE; 0 is the default): workgroup lanes / tile / sub-groups per workgroup. */
+/* Returns true if the deep kernels have to follow (false: the launch runs the deep list's items itself). */
 template <typename T, int RPL, bool IS_HELL, bool DEEP>
-static void launchRagged(hipStream_t stream, const SlabArgs<T>& a, int shape, bool tiled)
+static bool launchRagged(hipStream_t stream, const SlabArgs<T>& a, int shape, bool tiled)
 {
     constexpr int UNROLL = SPGPU_RAGGED_UNROLL(RPL);
     const long long subs = ((long long)a.rows + 31) / 32;
 #define SPGPU_RAGGED(WAVES, TILE, SUBS)                                                                               \
     hipLaunchKernelGGL((raggedSpmvKernel<T, RPL, IS_HELL, UNROLL, WAVES, TILE, SUBS, DEEP>),                          \
                        dim3((unsigned)((subs + (SUBS) - 1) / (SUBS))), dim3((WAVES) * kWave), 0, stream, a)
+#define SPGPU_RAGGED_Z(WAVES, TILE, SUBS, ZB)                                                                         \
+    hipLaunchKernelGGL((raggedSpmvKernel<T, RPL, IS_HELL, UNROLL, WAVES, TILE, SUBS, DEEP, ZB>),                      \
+                       dim3((unsigned)((subs + (SUBS) - 1) / (SUBS))), dim3((WAVES) * kWave), 0, stream, a)
     if (!tiled) {
         SPGPU_RAGGED(4, 0, 16);
-        return;
+        return true;
     }
     switch (shape) {
 #ifdef SPGPU_TUNING_VARIANTS
@@ -398,7 +479,11 @@ static void launchRagged(hipStream_t stream, const SlabArgs<T>& a, int shape, bo
     case 2: SPGPU_RAGGED(4, 49152, 32); break;
     case 3: SPGPU_RAGGED(4, 32768, 16); break;
 #endif
+    case 4: SPGPU_RAGGED_Z(8, 49152, 64, 17408); break; /* 2 048 rows per workgroup, results staged by destination */
+    case 5: SPGPU_RAGGED_Z(8, 49152, 32, 17408); break;
     default: SPGPU_RAGGED(8, 65536, 32); break;
     }
+    return true;
 #undef SPGPU_RAGGED
+#undef SPGPU_RAGGED_Z
 }

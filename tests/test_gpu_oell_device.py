@@ -266,13 +266,13 @@ def test_deep_queue_overflow_stays_correct(gpu, tuning):
         assert float((z - exact).abs().max()) <= 1e-12
 
 
-@pytest.mark.parametrize("shape,form", [(0, "auto"), (0, "gather")] + [pytest.param(k, "auto", marks=pytest.mark.skipif("not config._lab_build", reason="non-default kernel shape: -DSPGPU_TUNING_VARIANTS build")) for k in (1, 2, 3)])
+@pytest.mark.parametrize("shape,form", [(0, "auto"), (0, "gather"), (4, "auto"), (5, "auto")] + [pytest.param(k, "auto", marks=pytest.mark.skipif("not config._lab_build", reason="non-default kernel shape: -DSPGPU_TUNING_VARIANTS build")) for k in (1, 2, 3)])
 @pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
 @pytest.mark.parametrize("window,long_rows,pattern,hack", [(512, 40, "near", 32), (0, 0, "near", 64), (1024, 0, "random", 32), (256, 100, "near", 96)])
 def test_ragged_kernel_through_ridx_bit_exact(gpu, tuning, letter, shape, form, window, long_rows, pattern, hack):
     """The queue-driven kernel a row order selects (ragged_spmv.hip.h) with the deep split behind it: all four types,
-    hack sizes 32 / 64 / 96, every workgroup shape, tile and gathers, beta != 0 and in place; against the oracle in the
-    kernel's order (2 * rows-per-lane phases, items of 64 columns beyond the cap) bit for bit."""
+    hack sizes 32 / 64 / 96, every workgroup shape (4 and 5: results staged in LDS by destination and written in whole lines;
+    4: 2 048 rows per workgroup), tile and gathers, beta != 0 and in place; against the oracle in the kernel's order (2 * rows-per-lane phases, items of 64 columns beyond the cap) bit for bit."""
     import torch
     from spgpu_amd import capi, formats, synth
     tuning(SPGPU_RAGGED_SHAPE=shape)

@@ -48,7 +48,7 @@ def shape_of(form, ordered):
         return dict(group_rows=64, rows_per_lane=1, step=1, tail_lanes=0, phases=1)      # ascending k, nothing else
     if form.startswith(("share", "pipe")):
         return O.slab_shape(letter, "share")
-    if form.startswith("ragged"):
+    if form.startswith("ragged") or (form == "auto" and ordered):     # with a row order AUTO picks one of the queue kernel's shapes
         return O.slab_shape(letter, "ragged", 0, deep_cap=deep)
     if form.startswith("tile"):
         return O.slab_shape(letter, "xtile", int(form[4:]), deep_cap=deep)
@@ -153,7 +153,7 @@ def aligned_order(lengths, window, long_rows):
 
 
 if "powerlaw" in cases:
-    lengths = synth.power_law_lengths(n, mean=32.0, max_len=2048, seed=5)
+    lengths = synth.power_law_lengths(n, mean=32.0, max_len=int(os.environ.get("EXP_MAXLEN", "2048")), seed=5)   # EXP_MAXLEN: where do the long rows' costs start?
     for pattern in os.environ.get("EXP_PATTERNS", "near,random").split(","):
         rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 2048, letter, seed=5)
         torch.cuda.synchronize()
