@@ -17,6 +17,8 @@
  *   SPGPU_HDIA_BLOCK     HDIA workgroup size 256 / 512 (default) / 1024
  *   SPGPU_HDIA_NARROW    1: one row per lane even when 16-byte accesses are possible
  *   SPGPU_XCD_ORDER      HDIA: 0 hardware workgroup order (default), n: XCD-contiguous runs of n
+ *   SPGPU_RAGGED_SPLIT   ELL/HELL SpMV with a row order: columns per chunk of a 32-row sub-group that several wavefronts share
+ *                        (unset: about 96; 0: never cut; rounded up to what LDS can park; csrc/ragged_spmv.hip.h, SPLIT)
  *   SPGPU_SPMM_VARIANT   SpMM kernel shape (0 = default, see csrc/hell_spmm.hip)
  *   SPGPU_L1_NT          Level-1 streams non-temporal: 1 always, 0 never, unset: vectors beyond the Infinity Cache
  *   SPGPU_L1_BLOCKS      grid cap of the Level-1 kernels (default 16384)

@@ -651,11 +651,15 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
         const int l = rS ? rS[i] : maxNnz;                                                                    \
         return (P##_deep_group(rS, maxNnz, rows, i, deepCap) && l > deepCap) ? deepCap : l;                   \
     }                                                                                                         \
-    void orc_##P##spmv_deep(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
+    /* mainChunk > 0 (the queue kernel for ordered rows, csrc/ragged_spmv.hip.h SPLIT): a 32-row sub-group whose walked */  \
+    /* depth exceeds mainChunk is cut into chunks of mainChunk columns; a chunk's `phases` phase sums (by k mod phases, */   \
+    /* each ascending) are combined pairwise, and the chunk sums are added in chunk order -- every chunk of the sub-group */ \
+    /* for every one of its rows, a shorter row's later chunks being +0.  (No tail rows in that kernel: tailLanes 0.) */     \
+    void orc_##P##spmv_split(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,            \
                             const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \
                             const int* rIdx, int rows, const T* x, T beta, int baseIndex, int groupRows,      \
                             int rowsPerLane, int step, int tailLanes, int phases, int deepCap, int deepPhases,\
-                            int deepChunk)                                                                    \
+                            int deepChunk, int mainChunk)                                                     \
     {                                                                                                         \
         for (int g0 = 0; g0 < rows; g0 += groupRows) {                                                        \
             const int gEnd = g0 + groupRows < rows ? g0 + groupRows : rows;                                   \
@@ -700,6 +704,24 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                     head[0] = P##_add(head[0], P##_combine(part, 64));                                        \
                 }                                                                                             \
                 T total = P##_combine(head, phases);                                                          \
+                if (mainChunk > 0) {                                                                          \
+                    int walkedDepth = 0; /* of row i's 32-row sub-group */                                     \
+                    for (int r = i / 32 * 32; r < i / 32 * 32 + 32 && r < rows; ++r) {                         \
+                        const int l = P##_walked(rS, maxNnz, rows, r, deepCap);                               \
+                        if (l > walkedDepth) walkedDepth = l;                                                 \
+                    }                                                                                         \
+                    if (walkedDepth > mainChunk) {                                                            \
+                        for (int c0 = 0; c0 < walkedDepth; c0 += mainChunk) {                                 \
+                            T part[ORC_MAX_PHASES];                                                           \
+                            for (int p = 0; p < phases; ++p) part[p] = P##_zero();                            \
+                            for (int k = c0; k < len && k < c0 + mainChunk; ++k) {                            \
+                                const int col = rP[slot0 + (size_t)k * is] - baseIndex;                       \
+                                if (col >= 0) part[k % phases] = P##_fma(cM[slot0 + (size_t)k * vs], x[col], part[k % phases]); \
+                            }                                                                                 \
+                            total = c0 == 0 ? P##_combine(part, phases) : P##_add(total, P##_combine(part, phases)); \
+                        }                                                                                     \
+                    }                                                                                         \
+                }                                                                                             \
                 const int subDepth = P##_deep_group(rS, maxNnz, rows, i, deepCap);                            \
                 if (subDepth) {                                                                               \
                     /* deepSpmvKernel: columns >= deepCap in chunks of deepChunk; a chunk's deepPhases phase sums */ \
@@ -720,6 +742,15 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                 P##_store(z, y, rIdx ? rIdx[i] : i, alpha, total, beta);                                      \
             }                                                                                                 \
         }                                                                                                     \
+    }                                                                                                         \
+    void orc_##P##spmv_deep(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
+                            const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \
+                            const int* rIdx, int rows, const T* x, T beta, int baseIndex, int groupRows,      \
+                            int rowsPerLane, int step, int tailLanes, int phases, int deepCap, int deepPhases,\
+                            int deepChunk)                                                                    \
+    {                                                                                                         \
+        orc_##P##spmv_split(z, y, alpha, cM, rP, hackSize, hackOffsets, cMPitch, rPPitch, rS, maxNnz, rIdx, rows, x, beta, \
+                            baseIndex, groupRows, rowsPerLane, step, tailLanes, phases, deepCap, deepPhases, deepChunk, 0); \
     }                                                                                                         \
     void orc_##P##spmv_tail(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
                             const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \

@@ -286,6 +286,7 @@ void spgpuTuningReload(void)
     t.ragged = envInt("SPGPU_RAGGED", 1);
     t.raggedShape = envInt("SPGPU_RAGGED_SHAPE", 0);
     t.pipeGroups = envInt("SPGPU_PIPE_GROUPS", 0);
+    t.raggedSplit = envInt("SPGPU_RAGGED_SPLIT", -1);
     t.l1Nt = envInt("SPGPU_L1_NT", -1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);

@@ -83,6 +83,7 @@ template <typename T> struct SlabArgs {
     int xcdRun;                  /* raggedSpmvKernel: row blocks per XCD run (0: hardware order) */
     int pipeRanges;              /* pipeSpmvKernel: ranges per workgroup */
     int avgNnzPerRow;            /* the caller's hint (0: none) */
+    int split;                   /* raggedSpmvKernel: columns per chunk of a split sub-group (0: none) */
 };
 
 constexpr int kBlockThreads = 256;

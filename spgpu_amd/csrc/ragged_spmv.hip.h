@@ -24,6 +24,10 @@
  * Algorithmic bytes as for slabSpmvKernel, plus 4 per row for rIdx.
  */
 
+/* Most chunks a split sub-group may have (see SPLIT below): what the tightest tiled shape -- 48 KiB of LDS behind 2 048 rows --
+ * can park when every one of its sub-groups is split.  fp64 / complex fp32: 3, fp32: 6, complex fp64: 1 (never split). */
+template <typename T> constexpr int kRaggedMostChunks = 49152 / (int)sizeof(T) / 2048;
+
 template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int TILE_BYTES, int SUBS, bool DEEP, int ZBYTES = 0>
 __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4)))
 void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavefront workgroups per CU (what LDS admits) */
@@ -34,7 +38,9 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     constexpr int BLOCK = WAVES * kWave;
     constexpr int ROWS = SUBS * 32;
     constexpr bool XTILE = TILE_BYTES > 0;
-    constexpr int TILE_ELEMS = XTILE ? TILE_BYTES / (int)sizeof(T) : 1;
+    /* (the gather form has no tile, only room for the chunk sums of its split sub-groups: the sums must not depend on the form) */
+    constexpr int TILE_ELEMS = XTILE ? TILE_BYTES / (int)sizeof(T) : (kRaggedMostChunks<T> >= 2 ? SUBS * 32 * kRaggedMostChunks<T> : 1);
+    static_assert(TILE_ELEMS >= SUBS * 32 * kRaggedMostChunks<T> || kRaggedMostChunks<T> < 2, "room for every chunk sum");
     /* ZSTAGE: the workgroup's results wait in LDS, placed by destination, and leave in whole lines when its queue is empty.
      * The L2 does not merge stores over time (every store's bytes leave it at once): written from the lanes that hold the
      * sums, z[rIdx[r]] is one 8-byte fabric write per row -- 3 % of the kernel's time with the rows ordered in windows of
@@ -56,6 +62,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     __shared__ __attribute__((aligned(16))) T staged[ZW];
     __shared__ unsigned stagedMask[ZW / 32];
     __shared__ int lowestDest;
+    __shared__ int2 subFacts[SUBS]; /* first item of the sub-group; first parked chunk sum, or -1 (one chunk) */
     __shared__ unsigned bases[ROWS / RPL]; /* first slot of every RPL-row strip, in elements (hackOffsets is an int array: a slot
                                               number plus the offset inside the hack fits 32 unsigned bits; 64-bit from here on) */
     __shared__ int depths[SUBS];      /* longest walked row of every sub-group */
@@ -200,29 +207,70 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     }
 
     /* ---- the per-sub-group state of a lane, and the stage loads --------------------------------------------------- */
+    /* SPLIT (a.split > 0 columns): after the ordering every window has one sub-group some 250 columns deep at its head; walked
+     * by one wavefront that is ~21 stages, 90 us, while the other seven finish the window's remaining 63 sub-groups in ~50.  A
+     * sub-group deeper than a.split (and not deeper than deepCap: at most a few chunks) is therefore cut into chunks of a.split
+     * columns, each an item of its own; the chunk sums wait behind the x tile and are added in chunk order when the queue is
+     * empty (orc_?spmv_deep, mainChunk).  Every wavefront works the table out for itself, a lane per sub-group. */
+    const int split = a.split;
+    const int myDepthHere = lane < SUBS ? depths[lane] : 0;
+    const bool mySplit = split > 0 && myDepthHere > split && myDepthHere <= a.deepCap;
+    const int myChunks = lane < SUBS ? (mySplit ? (myDepthHere + split - 1) / split : 1) : 0;
+    int itemIncl = myChunks, parkIncl = mySplit ? myChunks : 0;
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+        const int items = __shfl_up(itemIncl, m, kWave), parks = __shfl_up(parkIncl, m, kWave);
+        itemIncl += lane >= m ? items : 0;
+        parkIncl += lane >= m ? parks : 0;
+    }
+    const int totalItems = __builtin_amdgcn_readfirstlane(__shfl(itemIncl, kWave - 1, kWave));
+    const int totalParks = __builtin_amdgcn_readfirstlane(__shfl(parkIncl, kWave - 1, kWave));
+    const int tileRoom = TILE_ELEMS - totalParks * 32; /* >= 0: the host sized a.split for it (launchRagged) */
+    T* const parked = tile + (tileRoom > 0 ? tileRoom : 0);
+    if (lane < SUBS)
+        subFacts[lane] = int2{itemIncl - myChunks, mySplit ? parkIncl - myChunks : -1}; /* the same values from every wavefront */
+    const unsigned long long splitOnes = __ballot(mySplit);
+
     struct Item {
         long long slab; /* first slot of this lane's strip */
-        int len[RPL];
+        int len[RPL];   /* cut at the end of the chunk */
         int longest;    /* of this lane's rows */
-        int depth;      /* of the sub-group (wave-uniform) */
+        int kEnd;       /* end of the chunk (wave-uniform) */
+        int s;          /* sub-group */
+        int park;       /* where the chunk sum waits, or -1: the sub-group is one item and finished on the spot */
     };
     struct Stage {
         Pack<T, RPL> v[UNROLL];
         Pack<int, RPL> c[UNROLL];
     };
-    auto loadItem = [&](int s, Item& it) {
-        it.slab = (long long)bases[s * LPC + sub];
+    /* item -> (sub-group, chunk); returns the chunk's first column */
+    auto loadItem = [&](int item, Item& it) -> int {
+        /* the lane's strip number, opaque here: the LDS addresses and the row pointer built from it below are loop-invariant
+         * per lane, and hoisted out of the stream loop they were kept in registers the loop does not have -- spilled, and
+         * re-read from scratch with a vmcnt(0) wait (which drains the prefetch) at every item */
+        int strip = sub;
+        asm volatile("" : "+v"(strip));
+        const int s = __popcll(__ballot(lane < SUBS && itemIncl <= item));
+        const int2 facts = subFacts[s];
+        const int chunk = item - __builtin_amdgcn_readfirstlane(facts.x);
+        const int parkFirst = __builtin_amdgcn_readfirstlane(facts.y);
+        const int depth = depths[s];
+        it.s = s;
+        it.park = parkFirst >= 0 ? parkFirst + chunk : -1;
+        it.kEnd = parkFirst >= 0 && (chunk + 1) * split < depth ? (chunk + 1) * split : depth;
+        it.slab = (long long)bases[s * LPC + strip];
         it.longest = 0;
 #pragma unroll
         for (int t = 0; t < RPL; ++t) {
-            it.len[t] = lens[s * 32 + sub * RPL + t];
+            it.len[t] = lens[s * 32 + strip * RPL + t];
             if (it.len[t] == 0xFFFF) { /* see lens: not cut (the sub-group has no deep slot), so the row's own length */
-                const long long r = blockRow0 + s * 32 + sub * RPL + t;
+                const long long r = blockRow0 + s * 32 + strip * RPL + t;
                 it.len[t] = a.rS ? a.rS[r] : a.maxNnz;
             }
+            it.len[t] = it.len[t] < it.kEnd ? it.len[t] : it.kEnd;
             it.longest = it.len[t] > it.longest ? it.len[t] : it.longest;
         }
-        it.depth = depths[s];
+        return parkFirst >= 0 ? chunk * split : 0;
     };
     auto fetch = [&](const Item& it, int kBase, Stage& st) {
 #pragma unroll
@@ -250,9 +298,10 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     struct Slot {
         Stage st;
         int len[RPL];
-        int s;      /* sub-group (>= SUBS: nothing, the stream has ended) */
+        int s;      /* sub-group (< 0: nothing, the stream has ended) */
+        int park;
         int kBase;
-        bool last;  /* last stage of its sub-group */
+        bool last;  /* last stage of its item */
     };
     auto grab = [&]() -> int {
         int got = 0;
@@ -261,33 +310,34 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         return __builtin_amdgcn_readfirstlane(got);
     };
     /* fetch cursor */
-    int fs = wave, fk = 0, fsThen = SUBS; /* fsThen: grabbed one sub-group ahead (after the prologue's barrier) */
+    int fItem = wave, fk = 0, fThen = totalItems; /* fThen: taken one item ahead (after the prologue's barrier) */
     Item fit;
-    loadItem(fs, fit);
+    if (fItem < totalItems)
+        fk = loadItem(fItem, fit);
     auto fetchNext = [&](Slot& slot) {
-        slot.s = fs;
-        slot.kBase = fk;
-        if (fs < SUBS) {
+        slot.s = -1;
+        slot.last = false;
+        if (fItem < totalItems) {
 #pragma unroll
             for (int t = 0; t < RPL; ++t)
                 slot.len[t] = fit.len[t];
+            slot.s = fit.s;
+            slot.park = fit.park;
+            slot.kBase = fk;
             fetch(fit, fk, slot.st);
             fk += STEP;
-            slot.last = fk >= fit.depth;
-            if (slot.last) { /* wavefront-uniform: on to the next sub-group */
-                fs = fsThen;
-                fk = 0;
-                if (fs < SUBS)
-                    loadItem(fs, fit);
-                fsThen = fs < SUBS ? grab() : SUBS;
+            slot.last = fk >= fit.kEnd;
+            if (slot.last) { /* wavefront-uniform: on to the next item */
+                fItem = fThen;
+                if (fItem < totalItems)
+                    fk = loadItem(fItem, fit);
+                fThen = fItem < totalItems ? grab() : totalItems;
             }
-        } else {
-            slot.last = false;
         }
     };
     Slot ring[AHEAD + 1];
 
-    fsThen = grab();
+    fThen = grab();
 #pragma unroll
     for (int i = 0; i < AHEAD; ++i)
         fetchNext(ring[i]); /* on their way while the tile is being placed and filled */
@@ -307,15 +357,15 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         }
         if (all.rows > 0 && all.lowest >= 0) {
             const long long span = (long long)all.highest - all.lowest + 1;
-            if (span <= TILE_ELEMS) {
+            if (span <= tileRoom) {
                 tileBase = all.lowest;
                 tileCount = (unsigned)span;
-            } else {
-                long long start = all.middles / all.rows - TILE_ELEMS / 2;
+            } else if (tileRoom > 0) {
+                long long start = all.middles / all.rows - tileRoom / 2;
                 start = start < all.lowest ? all.lowest : start;
-                start = start + TILE_ELEMS > (long long)all.highest + 1 ? (long long)all.highest + 1 - TILE_ELEMS : start;
+                start = start + tileRoom > (long long)all.highest + 1 ? (long long)all.highest + 1 - tileRoom : start;
                 tileBase = (int)start;
-                tileCount = TILE_ELEMS;
+                tileCount = (unsigned)tileRoom;
             }
         }
         constexpr int PIECE = 16 / (int)sizeof(T);
@@ -347,6 +397,27 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     for (int t = 0; t < RPL; ++t)
         sum[t] = zeroOf<T>();
 
+    /* the sum of row `rowInSub` of sub-group s over the columns walked here is complete */
+    auto finishRow = [&](int s, int rowInSub, T rowSum) {
+        const long long r = blockRow0 + s * 32 + rowInSub;
+        if (r >= a.rows)
+            return;
+        const int deepSlot = DEEP ? deepSlots[s] : -1;
+        if (deepSlot >= 0) {
+            a.deepPartials[(size_t)deepSlot * 32 + (size_t)rowInSub] = rowSum; /* the deep kernels finish the row */
+        } else if constexpr (ZSTAGE) {
+            const unsigned off = destOffset[s * 32 + rowInSub];
+            if (off != 0xFFFFu) {
+                staged[off] = mul(a.alpha, rowSum); /* beta * y joins when the line is written */
+            } else { /* beyond the staging buffer: the scattered store, its destination from global memory */
+                const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
+                a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, rowSum, a.beta, a.y[outRow]) : epilogue<false>(a.alpha, rowSum, a.beta, zeroOf<T>());
+            }
+        } else {
+            const int outRow = dests[s * 32 + rowInSub];
+            a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, rowSum, a.beta, a.y[outRow]) : epilogue<false>(a.alpha, rowSum, a.beta, zeroOf<T>());
+        }
+    };
     /* consume the stage in `cur`; request the stage AHEAD further on into `refill` (the slot consumed last) */
     auto step = [&](Slot& cur, Slot& refill) {
         T xv[UNROLL][RPL];
@@ -382,7 +453,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
                 }
             }
         }
-        const int s = cur.s;
+        const int s = cur.s, park = cur.park;
         const bool last = cur.last;
         fetchNext(refill); /* behind the x reads in issue order */
 #pragma unroll
@@ -391,7 +462,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
             for (int t = 0; t < RPL; ++t)
                 sum[t] = pick(use[u][t], mulAdd(cur.st.v[u].v[t], xv[u][t], sum[t]), sum[t]);
         }
-        if (last) { /* wavefront-uniform: the sub-group is complete */
+        if (last) { /* wavefront-uniform: the item is complete */
 #pragma unroll
             for (int m = LPC; m < kWave; m <<= 1) {
 #pragma unroll
@@ -399,28 +470,12 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
                     sum[t] = add(sum[t], laneXor(sum[t], m));
             }
             if (phase == 0) {
-                const int deepSlot = deepSlots[s];
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
-                    const long long r = blockRow0 + s * 32 + sub * RPL + t;
-                    if (r < a.rows) {
-                        if (DEEP && deepSlot >= 0) {
-                            a.deepPartials[(size_t)deepSlot * 32 + (size_t)(sub * RPL + t)] = sum[t];
-                        } else if constexpr (ZSTAGE) {
-                            const unsigned off = destOffset[s * 32 + sub * RPL + t];
-                            if (off != 0xFFFFu) {
-                                staged[off] = mul(a.alpha, sum[t]); /* beta * y joins when the line is written */
-                            } else { /* beyond the staging buffer: the scattered store, its destination from global memory */
-                                const int outRow = a.rIdx ? a.rIdx[r] : (int)r;
-                                a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
-                                                      : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
-                            }
-                        } else {
-                            const int outRow = dests[s * 32 + sub * RPL + t];
-                            a.z[outRow] = hasBeta ? epilogue<true>(a.alpha, sum[t], a.beta, a.y[outRow])
-                                                  : epilogue<false>(a.alpha, sum[t], a.beta, zeroOf<T>());
-                        }
-                    }
+                    if (park >= 0)
+                        parked[park * 32 + sub * RPL + t] = sum[t]; /* a chunk of a split sub-group: combined below */
+                    else
+                        finishRow(s, sub * RPL + t, sum[t]);
                 }
             }
 #pragma unroll
@@ -430,12 +485,30 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     };
     static_assert(AHEAD == 2, "the rotation below is written out for a ring of three");
     for (;;) { /* the ring rotates by name, not by copying registers */
-        if (ring[0].s >= SUBS) break;
+        if (ring[0].s < 0) break;
         step(ring[0], ring[2]);
-        if (ring[1].s >= SUBS) break;
+        if (ring[1].s < 0) break;
         step(ring[1], ring[0]);
-        if (ring[2].s >= SUBS) break;
+        if (ring[2].s < 0) break;
         step(ring[2], ring[1]);
+    }
+    if (splitOnes != 0ull) { /* workgroup-uniform (every wavefront computed the same table) */
+        __syncthreads();     /* every chunk sum is in LDS */
+        const int splitCount = __popcll(splitOnes);
+        for (int q0 = wave * 2; q0 < splitCount; q0 += WAVES * 2) { /* a half-wave per split sub-group */
+            const int q = q0 + (lane >> 5);
+            unsigned long long rest = splitOnes;
+            for (int skip = 0; skip < (q < splitCount ? q : 0); ++skip)
+                rest &= rest - 1;
+            const int s = __ffsll((long long)rest) - 1;
+            if (q < splitCount) {
+                const int first = subFacts[s].y, count = (depths[s] + split - 1) / split;
+                T total = parked[first * 32 + (lane & 31)];
+                for (int c = 1; c < count; ++c)
+                    total = add(total, parked[(first + c) * 32 + (lane & 31)]);
+                finishRow(s, lane & 31, total);
+            }
+        }
     }
     if constexpr (ZSTAGE) {
         __syncthreads(); /* every staged sum is in LDS */
@@ -458,10 +531,26 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
 #endif
 /* Shapes (SPGPU_RAGGED_SHAPE; 0 is the default): workgroup lanes / tile / sub-groups per workgroup. */
 /* Returns true if the deep kernels have to follow (false: the launch runs the deep list's items itself). */
+/* Columns per chunk of a split sub-group (raggedSpmvKernel, SPLIT): about 96 (8 stages of the 8-byte kernels), and large
+ * enough that the chunk sums of a workgroup whose sub-groups are ALL deepCap deep -- the hacks of set-aside long rows -- fit
+ * behind the x tile, which is of no use to such a workgroup anyway.  The SAME value for every shape and form (the sums must not
+ * depend on which of them AUTO takes): tests/oracle_api.py ragged_split restates this. */
+template <typename T> static int raggedSplit(int deepCap, int step, int asked)
+{
+    constexpr int most = kRaggedMostChunks<T>;
+    if (most < 2 || deepCap <= 0 || asked == 0)
+        return 0;
+    const int want = ((asked > 0 ? asked : 96) + step - 1) / step * step;
+    const int need = ((deepCap + most - 1) / most + step - 1) / step * step;
+    return want > need ? want : need;
+}
+
 template <typename T, int RPL, bool IS_HELL, bool DEEP>
-static bool launchRagged(hipStream_t stream, const SlabArgs<T>& a, int shape, bool tiled)
+static bool launchRagged(hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled)
 {
     constexpr int UNROLL = SPGPU_RAGGED_UNROLL(RPL);
+    SlabArgs<T> a = in;
+    a.split = raggedSplit<T>(a.deepCap, (kWave / (32 / RPL)) * UNROLL, spgpuTuning()->raggedSplit);
     const long long subs = ((long long)a.rows + 31) / 32;
 #define SPGPU_RAGGED(WAVES, TILE, SUBS)                                                                               \
     hipLaunchKernelGGL((raggedSpmvKernel<T, RPL, IS_HELL, UNROLL, WAVES, TILE, SUBS, DEEP>),                          \

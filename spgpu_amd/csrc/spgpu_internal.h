@@ -107,6 +107,7 @@ typedef struct SpgpuTuning {
     int ragged;      /* 1: the queue-driven kernel where the deep split is on */
     int raggedShape; /* 0 */
     int pipeGroups;  /* 0: one workgroup per CU (tests: fewer, so that small matrices run several blocks per workgroup) */
+    int raggedSplit; /* -1: about 96 columns per chunk; 0: sub-groups are never cut; > 0: columns per chunk (rounded up to what LDS can park) */
     int l1Nt;        /* -1: by size */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);

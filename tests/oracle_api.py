@@ -421,6 +421,10 @@ for _L, _T in SCALAR.items():
     _f.restype = None
     _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32, i32,
                    i32, i32, i32]
+    _f = getattr(orc, f"orc_{_LOW[_L]}spmv_split")
+    _f.restype = None
+    _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32, i32,
+                   i32, i32, i32, i32]
 
 DEEP_CAP = 256   # SPGPU_DEEP_CAP default
 SHARE_CHUNK = 48  # columns per item of shareSpmvKernel (every type)
@@ -430,7 +434,7 @@ DEEP_SHAPE = {"S": dict(deep_phases=8, deep_chunk=64), "D": dict(deep_phases=4, 
 
 
 def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_rows=128, rows_per_lane=2, step=8,
-              tail_lanes=16, phases=1, deep_cap=0, deep_phases=1, deep_chunk=1):
+              tail_lanes=16, phases=1, deep_cap=0, deep_phases=1, deep_chunk=1, main_chunk=0):
     """HELL (dict has hack_offsets) or ELL SpMV in the summation order of the tail-mode slab kernel; deep_cap > 0: with
     the deep split (32-row sub-groups deeper than deep_cap finished by deepSpmvKernel)."""
     L = mat["letter"]
@@ -439,15 +443,28 @@ def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_row
     ri = None if r_idx is None else np.ascontiguousarray(r_idx, np.int32)
     is_hell = "hack_offsets" in mat
     rs = mat["row_lengths"] if (is_hell or with_row_sizes) else None
-    getattr(orc, f"orc_{_LOW[L]}spmv_deep")(
+    getattr(orc, f"orc_{_LOW[L]}spmv_split")(
         _p(z), _p(yy), scalar(L, alpha), _p(mat["values"]), _p(mat["indices"]), mat["hack_size"] if is_hell else 0,
         _p(mat["hack_offsets"]) if is_hell else None, 0 if is_hell else mat["pitch"], 0 if is_hell else mat["pitch"],
         _p(rs), 0 if is_hell else mat["max_row"], _p(ri), mat["rows"], _p(np.ascontiguousarray(x, NP_DTYPE[L])),
-        scalar(L, beta), mat["base"], group_rows, rows_per_lane, step, tail_lanes, phases, deep_cap, deep_phases, deep_chunk)
+        scalar(L, beta), mat["base"], group_rows, rows_per_lane, step, tail_lanes, phases, deep_cap, deep_phases, deep_chunk,
+        main_chunk)
     return z
 
 
-def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0):
+def ragged_split(letter, step, deep_cap, asked=-1):
+    """Columns per chunk of a split sub-group in raggedSpmvKernel (csrc/ragged_spmv.hip.h raggedSplit): about 96, and large
+    enough that the chunk sums of a workgroup whose sub-groups are all deepCap deep fit behind the x tile of the tightest shape
+    (2 048 rows / 48 KiB).  The same value for every workgroup shape and for the gather form; complex fp64 never splits."""
+    most = (49152 // {"S": 4, "D": 8, "C": 8, "Z": 16}[letter]) // 2048
+    if most < 2 or deep_cap <= 0 or asked == 0:
+        return 0
+    want = -(-(asked if asked > 0 else 96) // step) * step
+    need = -(-(-(-deep_cap // most)) // step) * step
+    return max(want, need)
+
+
+def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0, split=-1):
     """spmv_tail parameters of the kernel the library runs for (type, x form, deep split): csrc/ellpack_spmv.hip
     launchSlabFamily / launchTiled.  None for the shapes without a tail (complex fp64 outside the deep split: 2 phases)."""
     rpl = {"S": 4, "D": 2, "C": 2, "Z": 1}[letter]
@@ -458,7 +475,9 @@ def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0):
                     deep_cap=SHARE_CHUNK, deep_phases=phases, deep_chunk=SHARE_CHUNK)
     if form == "ragged":   # raggedSpmvKernel: one wavefront per 32-row sub-group, 64 / (32 / rpl) phases, no tail rows
         phases = 2 * rpl
-        return dict(group_rows=32, rows_per_lane=rpl, step=phases * (2 if rpl >= 4 else 3), tail_lanes=0, phases=phases, **deep)
+        step = phases * (2 if rpl >= 4 else 3)
+        return dict(group_rows=32, rows_per_lane=rpl, step=step, tail_lanes=0, phases=phases,
+                    main_chunk=ragged_split(letter, step, deep_cap, split), **deep)
     if form == "xtile":
         if tile_shape == 1 and not deep:
             return dict(group_rows=32, rows_per_lane=rpl, step=4 * rpl, tail_lanes=16, phases=2 * rpl) if rpl > 1 else None

@@ -303,6 +303,46 @@ def test_ragged_kernel_through_ridx_bit_exact(gpu, tuning, letter, shape, form, 
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
 
 
+@pytest.mark.parametrize("split", [0, 48, 96, 150])
+@pytest.mark.parametrize("letter,shape,form", [("D", 0, "auto"), ("D", 4, "auto"), ("S", 4, "auto"), ("C", 0, "gather"), ("Z", 4, "auto")])
+def test_split_sub_groups_bit_exact(gpu, tuning, letter, shape, form, split):
+    """SPLIT of the queue kernel (ragged_spmv.hip.h): sub-groups deeper than SPGPU_RAGGED_SPLIT columns (default: about 96) and
+    not beyond the deep cap are walked as chunks by several wavefronts, the chunk sums added in chunk order -- the oracle's
+    mainChunk.  0 switches it off, 48 asks for more chunks than LDS parks for 8-byte types (rounded up by the library and by
+    oracle_api.ragged_split alike); window 256 puts a deep head into every workgroup, the long-row hacks are split AND deep;
+    complex fp64 never splits."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    tuning(SPGPU_RAGGED_SHAPE=shape, SPGPU_RAGGED_SPLIT=split)
+    n = 9000 + 7
+    real = {"S": "S", "D": "D", "C": "S", "Z": "D"}[letter]
+    lengths = np.minimum(synth.power_law_lengths(n, 14.0, 700, 4), 700)
+    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, "near", 400, real, seed=3)
+    if letter in "CZ":
+        vals_t = torch.complex(vals_t, torch.flip(vals_t, [0]))
+    h = formats.coo_to_ordered_hell_device(gpu, n, rows_t, cols_t, vals_t, letter, 32, 256, 300)
+    sub = dict(letter=letter, rows=n, values=h["cM"][:h["slots"]].cpu().numpy(), indices=h["rP"][:h["slots"]].cpu().numpy(),
+               hack_offsets=h["hack_offsets"].cpu().numpy(), hack_size=32, row_lengths=h["rS"][:n].cpu().numpy(), base=0)
+    r_idx = h["rIdx"].cpu().numpy()
+    x, y = synth.values_for(letter, 11, n), synth.values_for(letter, 12, n)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    shape_args = O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP, split=split)
+    if split == 0 or letter == "Z":
+        assert shape_args["main_chunk"] == 0
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_GATHER if form == "gather" else capi.FORM_AUTO)
+    try:
+        for alpha, beta, in_place in ((1.0, 0.0, False), (2.0, 1.0, True)):
+            dz = dy.clone() if in_place else torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            capi.hellspmv[letter](gpu, _dp(dz), _dp(dz if in_place else None), capi.scalar(letter, alpha),
+                                  _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), _dp(h["rIdx"]), 14, n,
+                                  _dp(dx), capi.scalar(letter, beta), 0)
+            torch.cuda.synchronize()
+            want = O.spmv_tail(sub, x, y if beta != 0 else None, alpha, beta, r_idx=r_idx, **shape_args)
+            assert dz.cpu().numpy().tobytes() == want.tobytes(), (alpha, beta, in_place)
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+
+
 @pytest.mark.parametrize("pattern,expect", [("banded", "strips"), ("near512", "xtile"), ("random", "gather")])
 def test_auto_form_settles_on_the_matrix(gpu, pattern, expect):
     """AUTO: sample wavefronts of every launch report what they saw and the next launch on the same arrays uses it --

@@ -216,3 +216,38 @@ def test_rows_permutation_and_level1():
     za = (a + 1j * b).astype(np.complex128)
     zb = (b - 1j * a).astype(np.complex128)
     assert abs(O.dot("Z", za, zb) - np.sum(za * zb)) <= 1e-11 * float(np.sum(np.abs(za * zb)))  # un-conjugated
+
+
+@pytest.mark.parametrize("name", [n for n in _cases() if n.startswith("powerlaw")])
+def test_kernel_order_restatements_match_extended_precision(golden_dir, name):
+    """The oracle in the summation orders of the kernels a row order selects (oracle_api.slab_shape: queue kernel with the
+    deep split and with sub-groups cut into chunks, share kernel) against the extended-precision product, on the ragged
+    fixtures; a chunk length beyond every row changes no bit, and a row permutation only moves the results."""
+    g = _load(golden_dir, name)
+    letter = O.LETTER_OF[g["coo_vals"].dtype]
+    base, hs = int(g["base"]), int(g["hack_size"])
+    alpha, beta = g["alpha"][()], g["beta"][()]
+    y = g["y"] if beta != 0 else None
+    n = int(g["n_rows"])
+    hell = dict(letter=letter, rows=n, values=g["hell_values"], indices=g["hell_indices"],
+                hack_offsets=g["hell_hack_offsets"], hack_size=hs, row_lengths=g["row_lengths"], base=base)
+    ell = dict(letter=letter, rows=n, values=g["ell_values"], indices=g["ell_indices"],
+               pitch=int(g["ell_pitch"]), max_row=int(g["ell_max_row"]), row_lengths=g["row_lengths"], base=base)
+    for mat in (hell, ell):
+        for cap, split in ((256, -1), (16, 0), (64, 24), (64, 1 << 20)):
+            shape = O.slab_shape(letter, "ragged", deep_cap=cap, split=split)
+            _check(O.spmv_tail(mat, g["x"], y, alpha, beta, **shape), g, letter)
+        _check(O.spmv_tail(mat, g["x"], y, alpha, beta, **O.slab_shape(letter, "share")), g, letter)
+        whole = O.spmv_tail(mat, g["x"], y, alpha, beta, **O.slab_shape(letter, "ragged", deep_cap=64, split=0))
+        never = O.spmv_tail(mat, g["x"], y, alpha, beta, **O.slab_shape(letter, "ragged", deep_cap=64, split=1 << 20))
+        assert whole.tobytes() == never.tobytes()
+    # through a row order: z[rIdx[r]] = row r (y gathered the same way)
+    r_idx = np.random.default_rng(1).permutation(n).astype(np.int32)
+    shape = O.slab_shape(letter, "ragged", deep_cap=64, split=24)
+    straight = O.spmv_tail(hell, g["x"], y, alpha, beta, **shape)
+    y_moved = None
+    if y is not None:
+        y_moved = np.empty_like(y)
+        y_moved[r_idx] = y
+    moved = O.spmv_tail(hell, g["x"], y_moved, alpha, beta, r_idx=r_idx, **shape)
+    assert moved[r_idx].tobytes() == straight.tobytes()

@@ -49,7 +49,7 @@ def shape_of(form, ordered):
     if form.startswith(("share", "pipe")):
         return O.slab_shape(letter, "share")
     if form.startswith("ragged") or (form == "auto" and ordered):     # with a row order AUTO picks one of the queue kernel's shapes
-        return O.slab_shape(letter, "ragged", 0, deep_cap=deep)
+        return O.slab_shape(letter, "ragged", 0, deep_cap=deep, split=int(os.environ.get("SPGPU_RAGGED_SPLIT", "-1")))
     if form.startswith("tile"):
         return O.slab_shape(letter, "xtile", int(form[4:]), deep_cap=deep)
     return O.slab_shape(letter, "gather", 0, deep_cap=deep)
@@ -82,6 +82,9 @@ def run(h, label, forms):
     call = lambda: capi.hellspmv[letter](handle, p(z), None, one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
                                          None if os.environ.get("EXP_DROP_RIDX") else p(r_idx), 32, rows, p(x), zero, 0)
     for full in forms:
+        name = full
+        full, _, split = full.partition("@")        # "ragged0@0": sub-groups never cut; "ragged4@48": chunks of 48 columns
+        os.environ["SPGPU_RAGGED_SPLIT"] = split or "-1"
         form, _, xcd = full.partition("x")          # "ragged0x4": shape 0 with runs of 4 row blocks per XCD
         os.environ["SPGPU_XCD_ORDER"] = xcd or os.environ.get("EXP_XCD_ORDER", "0")
         os.environ["SPGPU_X_TILE_SHAPE"] = form[4:] if form.startswith("tile") else "0"
@@ -105,7 +108,7 @@ def run(h, label, forms):
         with torch.cuda.stream(stream):
             call()
         stream.synchronize()
-        print(f"{letter} {label:46s} {full:10s} slots/nnz {h['slots'] / h['nnz']:.3f}  {t:.4f} ms  {alg / t * 1e-6:7.1f} GB/s  "
+        print(f"{letter} {label:46s} {name:10s} slots/nnz {h['slots'] / h['nnz']:.3f}  {t:.4f} ms  {alg / t * 1e-6:7.1f} GB/s  "
               f"{alg / t * 1e-6 / 8000:.3f} of 8 TB/s  {check(h, form)}", flush=True)
     capi.spgpuSetSpmvForm(handle, 0)
 
