@@ -56,6 +56,7 @@ template <typename T> struct SpmmArgs {
     int rows, baseIndex, hackSize;
     int count;      /* right-hand sides in this pass (<= KP*VEC) */
     int tileRows;   /* tiled kernel: X rows the LDS tile can hold */
+    int directFill; /* strip kernel: every 16-byte piece of a tile row is 16 valid, aligned bytes of X (global_load_lds) */
     long long ldX, ldYZ;
 };
 
@@ -459,6 +460,57 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
     T* const tile = reinterpret_cast<T*>(spmmLds);
     SpmmStage<T>* const stage = reinterpret_cast<SpmmStage<T>*>(spmmLds + kStripTileBytes) + wave;
     const unsigned hs = (unsigned)a.hackSize;
+    /* The tile fill: X rows first .. first + count - 1 into LDS.  Where whole 16-byte pieces line up (a.directFill, decided by
+     * the host) the copy goes straight from global memory into LDS (global_load_lds_dwordx4): no registers, no ds_write, and
+     * ALL of a lane's pieces in flight at once -- through registers (5 pieces per lane at a time beside the two trips
+     * already in flight) a 288-row window was two dependent round trips.  One wave-wide instruction writes 1 KiB of LDS in
+     * lane order from 64 per-lane addresses: lane -> LDS position is fixed, so the lane works out WHICH piece of X lands
+     * there (the inverse of tileOffset); only whole wavefronts take it, the ragged end goes through registers. */
+    auto fillTile = [&](int first, int count) {
+        constexpr int PIECES_PER_ROW = ROW_BYTES >= 16 ? ROW_BYTES / 16 : 1;
+        constexpr int PIECE_ELEMS = 16 / (int)sizeof(T);
+        if (ROW_BYTES >= 16 && a.directFill) {
+            const int lines = (count + ROWS_PER_LINE - 1) / ROWS_PER_LINE;
+            const int slots = lines * 16; /* 16-byte slots of LDS, in address order */
+            for (int s0 = wave * kWave; s0 < slots; s0 += kSpmmThreads) { /* wavefront-uniform */
+                const int slot = s0 + lane;
+                const int line = slot >> 4, q = (slot & 15) / PIECES_PER_ROW, piece = slot % PIECES_PER_ROW;
+                const int r = line * ROWS_PER_LINE + ((q ^ ((line * ROWS_PER_LINE) >> 3)) & (ROWS_PER_LINE - 1));
+                const bool live = slot < slots && r < count;
+                const T* from = a.X + (long long)(first + (live ? r : 0)) * a.ldX + piece * PIECE_ELEMS;
+                if (__ballot(live) == ~0ull) {
+#if defined(__HIP_DEVICE_COMPILE__) /* the host pass of hipcc parses the kernel body too and has no such builtin */
+                    __builtin_amdgcn_global_load_lds(from, reinterpret_cast<unsigned char*>(tile) + (size_t)slot * 16, 16, 0, 0);
+#endif
+                } else if (live) {
+                    const Pack<T, PIECE_ELEMS> w = loadPack<false, T, PIECE_ELEMS>(from);
+                    storePack<T, PIECE_ELEMS>(reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(tile) + (size_t)slot * 16), w);
+                }
+            }
+            return;
+        }
+        /* KP lanes copy one X row, VEC elements each; FILL loads per lane in flight */
+        constexpr int FILL = 5;
+        const int pieces = count * KP;
+        for (int i0 = threadIdx.x; i0 < pieces; i0 += FILL * kSpmmThreads) {
+            Pack<T, VEC> part[FILL];
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) {
+                const int i = i0 + f * kSpmmThreads;
+                const int r = i / KP, piece = i % KP;
+                if (i < pieces && piece * VEC < a.count)
+                    part[f] = loadPack<false, T, VEC>(a.X + (long long)(first + r) * a.ldX + piece * VEC);
+            }
+#pragma unroll
+            for (int f = 0; f < FILL; ++f) {
+                const int i = i0 + f * kSpmmThreads;
+                const int r = i / KP, piece = i % KP;
+                if (i < pieces && piece * VEC < a.count)
+                    storePack<T, VEC>(reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(tile) + tileOffset(r)) + piece * VEC, part[f]);
+            }
+        }
+    };
+
 
     /* ---- index role ---- */
     const int iCol = lane >> 4, iHalf = (lane >> 3) & 1, iQ = lane & 7;
@@ -525,6 +577,28 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
             }
         }
     };
+    struct Trip {
+        Pack<int, 4> idx[TRIP];
+        Pack<T, CR> coef[TRIP * COEF_LOADS];
+    };
+    auto loadTripCoef = [&](int k0, Trip& t) {
+#pragma unroll
+        for (int s = 0; s < TRIP; ++s) {
+#pragma unroll
+            for (int j = 0; j < COEF_LOADS; ++j) {
+                const int kc = k0 + kStageCols * s + COLS_PER_COEF_LOAD * j + cCol;
+                if (kc < cLenMax) {
+                    t.coef[s * COEF_LOADS + j] = loadPack<true, T, CR>(cBase + (long long)kc * hs);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CR; ++e)
+                        t.coef[s * COEF_LOADS + j].v[e] = zeroOf<T>();
+                }
+            }
+        }
+    };
+    constexpr int STEP = kStageCols * TRIP;
+    Trip cur, next;
     int lo = 0x7fffffff, hi = -1;
     /* The indices of the first HEAD*4 slab columns are requested at once and stay in registers: the accumulation
      * below takes them from there instead of reading them a second time. */
@@ -569,10 +643,6 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
     }
     const bool useTile = fitsSoFar && hi >= lo && (long long)hi - lo < a.tileRows; /* workgroup-uniform */
 
-    struct Trip {
-        Pack<int, 4> idx[TRIP];
-        Pack<T, CR> coef[TRIP * COEF_LOADS];
-    };
     auto loadTrip = [&](int k0, Trip& t) {
 #pragma unroll
         for (int s = 0; s < TRIP; ++s) {
@@ -600,33 +670,27 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
             }
         }
     };
-    constexpr int STEP = kStageCols * TRIP;
-    Trip cur, next;
+    auto loadTripIdx = [&](Trip& t) { /* of the first trips: from the registers of the prologue */
+        static_assert(2 * TRIP <= HEAD, "the first two trips' indices are in the head");
+#pragma unroll
+        for (int s = 0; s < TRIP; ++s) {
+            t.idx[s] = head[0];
+#pragma unroll
+            for (int u = 0; u + 1 < HEAD; ++u)
+                head[u] = head[u + 1];
+        }
+    };
     if (useTile) {
         /* the first two trips' coefficients are requested before the tile is filled: one memory round trip for both */
-        loadTrip(0, cur);
-        loadTrip(STEP, next);
-        /* KP lanes copy one X row, VEC elements (16 bytes) each; FILL loads per lane in flight */
-        constexpr int FILL = 5;
-        const int pieces = (hi - lo + 1) * KP;
-        for (int i0 = threadIdx.x; i0 < pieces; i0 += FILL * kSpmmThreads) {
-            Pack<T, VEC> part[FILL];
-#pragma unroll
-            for (int f = 0; f < FILL; ++f) {
-                const int i = i0 + f * kSpmmThreads;
-                const int r = i / KP, piece = i % KP;
-                if (i < pieces && piece * VEC < a.count)
-                    part[f] = loadPack<false, T, VEC>(a.X + (long long)(lo + r) * a.ldX + piece * VEC);
-            }
-#pragma unroll
-            for (int f = 0; f < FILL; ++f) {
-                const int i = i0 + f * kSpmmThreads;
-                const int r = i / KP, piece = i % KP;
-                if (i < pieces && piece * VEC < a.count)
-                    storePack<T, VEC>(reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(tile) + tileOffset(r)) + piece * VEC, part[f]);
-            }
-        }
+        loadTripCoef(0, cur);
+        loadTripCoef(STEP, next);
+        loadTripIdx(cur);
+        loadTripIdx(next);
+        fillTile(lo, hi - lo + 1);
     }
+    /* (global_load_lds retires on vmcnt like any load, and the barrier below is what hands the tile to the other wavefronts:
+     * the wait is spelled out rather than left to whatever else happens to be waited for here) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     T sum[KP][VEC];
@@ -676,6 +740,9 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
             for (int j = 0; j < COEF_LOADS; ++j)
                 storePack<T, CR>(&stage->coef[COLS_PER_COEF_LOAD * j + cCol][32 * cHalf + CR * cQ], t.coef[s * COEF_LOADS + j]);
         };
+        /* (Tried: the offsets -- and the coefficients -- of the next 4 rows read one step ahead, so that a wavefront does not go
+         * through two dependent LDS round trips per 8 fused multiply-adds.  Offsets only: within the noise; both: +12 registers
+         * at 168, spills inside this loop, 0.97 ms against 0.65.) */
         auto consume = [&](auto allPresent) {
             constexpr bool ALL_PRESENT = decltype(allPresent)::value;
 #pragma unroll
@@ -706,7 +773,6 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
                 }
             }
         };
-
         auto runTrip = [&](const Trip& t, int k0, auto mode) {
 #pragma unroll
             for (int s = 0; s < TRIP; ++s) {
@@ -747,6 +813,9 @@ template <typename T, int TRIP, int VEC = 2> static void launchSpmmStrips(hipStr
     const long long groups = ((long long)a.rows + kWave - 1) / kWave;
     const unsigned blocks = (unsigned)((groups + kSpmmThreads / kWave - 1) / (kSpmmThreads / kWave));
     a.tileRows = kStripTileBytes / (8 * VEC * (int)sizeof(T));
+    /* whole tile rows of valid bytes: all KP * VEC right-hand sides present, rows of X 16-byte aligned */
+    a.directFill = a.count == 8 * VEC && (8 * VEC * sizeof(T)) % 16 == 0 && (uintptr_t)a.X % 16 == 0 &&
+                   (a.ldX * (long long)sizeof(T)) % 16 == 0 && spgpuTuning()->spmmVariant != 10;
     const size_t lds = kStripTileBytes + (kSpmmThreads / kWave) * sizeof(SpmmStage<T>);
     hipLaunchKernelGGL((hellSpmmStripKernel<T, TRIP, VEC>), dim3(blocks), dim3(kSpmmThreads), lds, stream, a);
 }
@@ -794,6 +863,7 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
         a.ldX = ldX;
         a.ldYZ = ldYZ;
         a.tileRows = 0;
+        a.directFill = 0;
         const bool pairs = pairsOk && a.count % 2 == 0;
         /* 16-byte loads of whole 32-row half columns */
         const bool strips = pairs && hackSize % 32 == 0 && (uintptr_t)cM % 16 == 0 && (uintptr_t)rP % 16 == 0;

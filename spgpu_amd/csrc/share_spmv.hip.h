@@ -452,6 +452,7 @@ __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4
             }
             if (pieces * PIECE + tid < tileCount)
                 buffer[pieces * PIECE + tid] = from[pieces * PIECE + tid];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* global_load_lds retires on vmcnt; the barrier hands the tile over */
             __syncthreads();
         }
 #ifdef SPGPU_TRACE_BLOCKS
