@@ -568,8 +568,16 @@ static bool launchRagged(hipStream_t stream, const SlabArgs<T>& in, int shape, b
     case 2: SPGPU_RAGGED(4, 49152, 32); break;
     case 3: SPGPU_RAGGED(4, 32768, 16); break;
 #endif
-    case 4: SPGPU_RAGGED_Z(8, 49152, 64, 17408); break; /* 2 048 rows per workgroup, results staged by destination */
-    case 5: SPGPU_RAGGED_Z(8, 49152, 32, 17408); break;
+    case 4: /* 2 048 rows per workgroup, results staged by destination */
+    case 5: /* 1 024 rows, staged */
+        if constexpr (sizeof(T) <= 8) { /* (16-byte elements: tile + staging leave room for one workgroup per CU -- the default shape) */
+            if (shape == 4)
+                SPGPU_RAGGED_Z(8, 49152, 64, 17408);
+            else
+                SPGPU_RAGGED_Z(8, 49152, 32, 17408);
+            break;
+        }
+        [[fallthrough]];
     default: SPGPU_RAGGED(8, 65536, 32); break;
     }
     return true;
