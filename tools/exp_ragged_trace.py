@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""GPU box experiment (needs the -DSPGPU_TRACE_BLOCKS build, SPGPU_LIB=...): the queue kernel (raggedSpmvKernel) on the ordered
+power-law matrix: start, tile-in-place and end of every workgroup -> how much of the launch is prologue, stream, ramp and tail.
+  python tools/exp_ragged_trace.py [rows] [window:long] [powerlaw|even] ; EXP_PATTERN=near|band ; SPGPU_RAGGED_SHAPE=0|4|5"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+os.environ["SPGPU_RAGGED"] = "1"
+from spgpu_amd import capi, formats, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+window, long_rows = (int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "2048:256").split(":"))
+case = sys.argv[3] if len(sys.argv) > 3 else "powerlaw"
+shape = int(os.environ.get("SPGPU_RAGGED_SHAPE", "0"))
+rows_per_group = 2048 if shape == 4 else 1024
+handle = capi.create_handle(0)
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+if case == "powerlaw":
+    lengths = synth.power_law_lengths(n, mean=32.0, max_len=2048, seed=5)
+else:
+    lengths = np.random.default_rng(1).integers(24, 41, size=n).astype(np.int32)
+coo = synth.ragged_coo_on_device(lengths, n, os.environ.get("EXP_PATTERN", "band"), 2048, "D", seed=5)
+h = formats.coo_to_ordered_hell_device(handle, n, *coo, "D", 32, window, long_rows)
+x = synth.device_vector(n, "D", 3)
+z = torch.zeros(n, dtype=torch.float64, device="cuda")
+groups = (n + rows_per_group - 1) // rows_per_group
+trace = torch.zeros(3 * groups + 16, dtype=torch.int64, device="cuda")
+capi.lib.spgpuDebugSetTrace.argtypes = [C.c_void_p]
+call = lambda: capi.hellspmv["D"](handle, p(z), None, 1.0, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]), p(h["rIdx"]), 32, n,
+                                  p(x), 0.0, 0)
+for _ in range(3):
+    call()
+torch.cuda.synchronize()
+trace.zero_()
+torch.cuda.synchronize()
+capi.lib.spgpuDebugSetTrace(p(trace))
+call()
+torch.cuda.synchronize()
+capi.lib.spgpuDebugSetTrace(None)
+t = trace[:3 * groups].view(groups, 3).cpu().numpy().astype(np.float64)
+t0 = t[:, 0].min()
+start, end, tiled = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0
+span = end.max()
+life, prologue = end - start, tiled - start
+slots = 512.0
+print(f"{case} {os.environ.get('EXP_PATTERN', 'band')} shape {shape}: {groups} workgroups, main kernel span {span:.1f} us")
+print(f"  workgroup life: min {life.min():.1f} median {np.median(life):.1f} p90 {np.percentile(life, 90):.1f} max {life.max():.1f} us;"
+      f" prologue (start -> tile in place): median {np.median(prologue):.1f} p90 {np.percentile(prologue, 90):.1f} us")
+print(f"  occupancy of the {slots:.0f} workgroup slots over the span: {life.sum() / (slots * span):.3f} resident,"
+      f" {(end - tiled).sum() / (slots * span):.3f} streaming, {prologue.sum() / (slots * span):.3f} in the prologue")
+last_start = start.max()
+print(f"  last workgroup starts at {last_start:.1f} us ({span - last_start:.1f} us before the end); resident workgroups at that moment "
+      f"{int(((start <= last_start) & (end > last_start)).sum())}; area idle after it: "
+      f"{(slots * (span - last_start) - np.clip(end - np.maximum(start, last_start), 0, None).sum()) / (slots * span):.3f} of the launch")
+edges = np.linspace(0, span, 21)
+res = [int(((start <= (a + b) / 2) & (end > (a + b) / 2)).sum()) for a, b in zip(edges[:-1], edges[1:])]
+print("  resident workgroups at 20 moments:", res)
+heavy = np.argsort(life)[-5:]
+print("  longest-lived workgroups:", [(int(b), round(float(start[b]), 1), round(float(life[b]), 1)) for b in heavy])
