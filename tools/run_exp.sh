@@ -1,8 +1,11 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-export SPGPU_LIB=/root/repo/spgpu_amd/lib_ab/libspgpu.so
-for shape in 4 0; do
-SPGPU_RAGGED_SHAPE=$shape EXP_PATTERN=band timeout -k 10 300 python3 tools/exp_ragged_trace.py 2>&1 | grep -v amdgpu.ids || exit 1
+timeout -k 10 600 python3 -m pytest tests/test_gpu_spmm.py tests/test_gpu_sharded_c.py -q -m gpu -x 2>&1 | tail -3 || exit 1
+for round in 1 2; do
+for L in lib_ab lib; do
+echo "== $L"
+SPGPU_LIB=/root/repo/spgpu_amd/$L/libspgpu.so VARIANTS=0 timeout -k 10 300 python3 tools/ab_spmm.py banded window 2>&1 | grep spmm || exit 1
+SPGPU_LIB=/root/repo/spgpu_amd/$L/libspgpu.so RHS=8 VARIANTS=0 timeout -k 10 300 python3 tools/ab_spmm.py banded 2>&1 | grep spmm || exit 1
 done
-SPGPU_RAGGED_SHAPE=4 EXP_PATTERN=band timeout -k 10 300 python3 tools/exp_ragged_trace.py 10000000 2048:256 even 2>&1 | grep -v amdgpu.ids || exit 1
+done
