@@ -32,6 +32,19 @@
 extern "C" {
 #endif
 
+/*
+ * The deep list.  An ELL/HELL SpMV that is given a row order (rIdx) hands the columns beyond SPGPU_DEEP_CAP of its deepest
+ * 32-row sub-groups to two small kernels through a list the handle owns (one per stream, 8 192 sub-groups / 20 480 items of 64
+ * columns).  A matrix with more such sub-groups than the list holds is still multiplied correctly -- the surplus is summed by
+ * the main kernel -- but WHICH sub-groups are surplus depends on the order in which workgroups register, and they are added
+ * in the plain order of the kernel, not in the deep order: for such a call z is within the tolerance of every other form but
+ * is not reproducible bit for bit from run to run, and is not the bit pattern the oracle restates.  spgpuDeepListOverflows
+ * says how many completed calls of the handle that was true for (0 for every matrix the tests and benches use, whose long
+ * rows were set aside by spgpuOellOrderDevice; a matrix ordered with longRows = 0 can overflow).  Remedy: a larger
+ * SPGPU_DEEP_CAP, or an order that sets the long rows aside.
+ */
+int spgpuDeepListOverflows(spgpuHandle_t handle);
+
 void spgpuTuningReload(void);
 /* 1 if the library was built with -DSPGPU_TUNING_VARIANTS: the non-default kernel shapes (SPGPU_SPMV_VARIANT, SPGPU_X_TILE_SHAPE,
  * SPGPU_RAGGED_SHAPE, SPGPU_RAGGED=0) exist only in such a build; the product build carries the defaults and ignores those knobs. */

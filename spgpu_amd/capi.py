@@ -253,6 +253,7 @@ for _L in "SD":
 FORM_AUTO, FORM_GATHER, FORM_STRIPS, FORM_XTILE, FORM_SWEEP = range(5)
 spgpuSetSpmvForm = _decl("spgpuSetSpmvForm", None, [Handle, i32])
 spgpuGetSpmvForm = _decl("spgpuGetSpmvForm", i32, [Handle])
+spgpuDeepListOverflows = _decl("spgpuDeepListOverflows", i32, [Handle])
 spgpuGetLastSpmvForm = _decl("spgpuGetLastSpmvForm", i32, [Handle])
 spgpuTuningVariantsBuilt = _decl("spgpuTuningVariantsBuilt", i32, [])
 spgpuHellSpmvForm = _decl("spgpuHellSpmvForm", i32, [Handle, i32, ptr, i32, ptr, ptr, i32, i32])

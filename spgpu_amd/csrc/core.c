@@ -70,10 +70,10 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     if (err == hipSuccess)
         err = hipHostMalloc(&h->reduceHost, SPGPU_REDUCE_SCRATCH_BYTES, hipHostMallocDefault);
     if (err == hipSuccess)
-        err = hipHostMalloc((void**)&h->formFeedback, (SPGPU_FEEDBACK_ENTRIES + 1) * SPGPU_FEEDBACK_SAMPLES * sizeof(int),
+        err = hipHostMalloc((void**)&h->formFeedback, (SPGPU_FEEDBACK_ENTRIES + 2) * SPGPU_FEEDBACK_SAMPLES * sizeof(int),
                             hipHostMallocDefault);
     if (err == hipSuccess)
-        memset(h->formFeedback, 0, (SPGPU_FEEDBACK_ENTRIES + 1) * SPGPU_FEEDBACK_SAMPLES * sizeof(int));
+        memset(h->formFeedback, 0, (SPGPU_FEEDBACK_ENTRIES + 2) * SPGPU_FEEDBACK_SAMPLES * sizeof(int));
     hipSetDevice(previous);
 
     if (err != hipSuccess) {
@@ -231,6 +231,18 @@ spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, SpgpuDeepList* list)
 int* spgpuAnalyseWords(spgpuHandle_t pHandle)
 {
     return spgpuPrivate(pHandle)->formFeedback + SPGPU_FEEDBACK_ENTRIES * SPGPU_FEEDBACK_SAMPLES;
+}
+
+/* Pinned words the deep kernels report into (ellpack_spmv.hip deepFinishKernel): [0] calls whose deep list overflowed,
+ * [1] / [2] the entries / items the last such call asked for. */
+int* spgpuDeepOverflowWords(spgpuHandle_t pHandle)
+{
+    return spgpuPrivate(pHandle)->formFeedback + (SPGPU_FEEDBACK_ENTRIES + 1) * SPGPU_FEEDBACK_SAMPLES;
+}
+
+int spgpuDeepListOverflows(spgpuHandle_t pHandle)
+{
+    return ((volatile int*)spgpuDeepOverflowWords(pHandle))[0];
 }
 
 /* ---- per-handle kernel-form hint (include/spgpu/tuning.h) ---- */

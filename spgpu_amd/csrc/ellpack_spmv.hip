@@ -80,6 +80,7 @@ template <typename T> struct SlabArgs {
     int* deepItemEntry;          /* [SPGPU_DEEP_ITEMS] */
     T* deepPartials;             /* [SPGPU_DEEP_ENTRIES][32] row sums over the columns < deepCap */
     T* deepItemSums;             /* [SPGPU_DEEP_ITEMS][32] */
+    int* deepOverflow;           /* pinned: calls that overflowed the list, and what the last of them asked for */
     int xcdRun;                  /* raggedSpmvKernel: row blocks per XCD run (0: hardware order) */
     int pipeRanges;              /* pipeSpmvKernel: ranges per workgroup */
     int avgNnzPerRow;            /* the caller's hint (0: none) */
@@ -828,6 +829,13 @@ __global__ __launch_bounds__(kBlockThreads) void deepFinishKernel(const SlabArgs
     if (threadIdx.x == 0) {
         const int ticket = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_TICKET], 1);
         if (ticket == (int)gridDim.x - 1) {
+            /* a list that overflowed: say so where the host can see it (spgpuDeepListOverflows, include/spgpu/tuning.h) */
+            const int handedOut = a.deepHeader[SPGPU_DEEP_HEAD_ITEMS];
+            if (a.deepOverflow && (registered > SPGPU_DEEP_ENTRIES || handedOut > SPGPU_DEEP_ITEMS)) {
+                a.deepOverflow[1] = registered;
+                a.deepOverflow[2] = handedOut;
+                a.deepOverflow[0] = a.deepOverflow[0] + 1; /* one writer per call, calls of a stream in order */
+            }
             a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES] = 0;
             a.deepHeader[SPGPU_DEEP_HEAD_ITEMS] = 0;
             a.deepHeader[SPGPU_DEEP_HEAD_TICKET] = 0;
@@ -1253,6 +1261,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     a.deepItemEntry = nullptr;
     a.deepPartials = nullptr;
     a.deepItemSums = nullptr;
+    a.deepOverflow = spgpuDeepOverflowWords(handle);
     bool noDeepList = false;
     if (deepSplit) {
         SpgpuDeepList list;

@@ -41,7 +41,7 @@ typedef struct SpgpuPrivateHandle {
     int deepStreams;
     int lastSpmvForm;         /* form of the most recent ELL/HELL SpMV launch (diagnostic, atomic) */
 } SpgpuPrivateHandle;
-#define SPGPU_FEEDBACK_ENTRIES 8 /* + one more group of words behind them for spgpu?SpmvForm */
+#define SPGPU_FEEDBACK_ENTRIES 8 /* + one more group of words behind them for spgpu?SpmvForm, and one for the deep list's overflow report */
 #define SPGPU_FEEDBACK_SAMPLES 4
 
 static inline SpgpuPrivateHandle* spgpuPrivate(spgpuHandle_t h)
@@ -114,6 +114,7 @@ const SpgpuTuning* spgpuTuning(void);
 
 /* Pinned words for the synchronous analysis calls (spgpuHellSpmvForm / spgpuEllSpmvForm): one analysis of a handle at a time. */
 int* spgpuAnalyseWords(spgpuHandle_t h);
+int* spgpuDeepOverflowWords(spgpuHandle_t h);
 
 #ifdef __cplusplus
 }

@@ -257,13 +257,21 @@ def test_deep_queue_overflow_stays_correct(gpu, tuning):
     x = synth.device_vector(n, "D", 5)
     z = torch.empty(n, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
-    for _ in range(2):
+    before = capi.spgpuDeepListOverflows(gpu)
+    for call in range(2):
         capi.hellspmv["D"](gpu, _dp(z), None, capi.scalar("D", 1.0), _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]),
                            _dp(h["rS"]), None, 3, n, _dp(x), capi.scalar("D", 0.0), 0)
         torch.cuda.synchronize()
         cols = h["rP"].view(n // 32, 3, 32).to(torch.int64)
         exact = (h["cM"].view(n // 32, 3, 32) * x[cols]).sum(dim=1).reshape(-1)
         assert float((z - exact).abs().max()) <= 1e-12
+        assert capi.spgpuDeepListOverflows(gpu) == before + call + 1      # the handle says so (include/spgpu/tuning.h)
+    # a call whose list does not overflow leaves the count alone
+    tuning(SPGPU_DEEP_SPLIT=1, SPGPU_DEEP_CAP=2)
+    capi.hellspmv["D"](gpu, _dp(z[:6400]), None, capi.scalar("D", 1.0), _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]),
+                       _dp(h["rS"]), None, 3, 6400, _dp(x), capi.scalar("D", 0.0), 0)
+    torch.cuda.synchronize()
+    assert capi.spgpuDeepListOverflows(gpu) == before + 2
 
 
 @pytest.mark.parametrize("shape,form", [(0, "auto"), (0, "gather"), (4, "auto"), (5, "auto")] + [pytest.param(k, "auto", marks=pytest.mark.skipif("not config._lab_build", reason="non-default kernel shape: -DSPGPU_TUNING_VARIANTS build")) for k in (1, 2, 3)])
