@@ -282,9 +282,11 @@ def bench_powerlaw(args, handle, stream, dev, rows):
                 out[f"{pattern}_vendor_context"] = vendor().coo_context(stream, rows, rows, lengths, coo[1], coo[2], x, torch.empty_like(z))
             except Exception as error:  # noqa: BLE001
                 out[f"{pattern}_vendor_context"] = repr(error)
-        for name, ordered in ((("sorted", True),) if pattern == "band" else (("plain", False), ("sorted", True))):
+        # "sorted_aligned": spgpuOellOrderAlignedDevice -- every window of the order is one 2 048-row workgroup (include/spgpu/ell_conv.h)
+        for name, ordered in ({"band": (("sorted", True), ("sorted_aligned", True)), "near": (("plain", False), ("sorted", True), ("sorted_aligned", True)),
+                               "random": (("plain", False), ("sorted", True))}[pattern]):
             t0 = time.perf_counter()
-            h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, 2048, 256, order=ordered)
+            h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, 2048, 256, order=ordered, aligned=name.endswith("aligned"))
             build_s = time.perf_counter() - t0
             # form AUTO throughout: through rIdx the tile form falls back to gathers column by column, and on scattered
             # columns it runs within 1 % of the plain gather form (tools/exp_tile.py, ragged0 vs raggedg)
@@ -646,9 +648,10 @@ def run_spmv(args, rank, world):
             out["configs"] = configs
             pl = configs.get("powerlaw_fp64", {})
             target = {name: dict(ms=pl[name]["ms"], frac=pl[name]["frac"], slots_per_nnz=pl[name]["slots_per_nnz"], parity=pl[name]["parity"])
-                      for name in ("band_sorted", "near_sorted", "near_plain") if isinstance(pl.get(name), dict)}
+                      for name in ("band_sorted", "band_sorted_aligned", "near_sorted", "near_sorted_aligned", "near_plain") if isinstance(pl.get(name), dict)}
             target["what"] = ("north_star target: spgpuDhellspmv, fp64, 10 M rows, power-law lengths (mean 32, max 2048), rows ordered "
-                              "on the device (windows of 2048, rows > 256 set aside) and run through rIdx; frac = algorithmic bytes / "
+                              "on the device (windows of 2048, rows > 256 set aside) and run through rIdx; *_aligned: the order whose windows "
+                              "coincide with the kernel's 2048-row workgroups (spgpuOellOrderAlignedDevice); frac = algorithmic bytes / "
                               "time / 8 TB/s; bar 0.70")
             out["config"]["north_star_target"] = target
             out["target"] = target

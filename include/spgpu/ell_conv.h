@@ -50,6 +50,14 @@ void ellToOell(int* rIdx, void* dstEllValues, int* dstEllIndices, int* dstRs, co
  *                one of their hacks would come from everywhere (every x gather a cache line from memory). */
 #define SPGPU_OELL_LONG_WINDOW_FACTOR 32
 void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows);
+/* The same with the windows of the shorter rows ALIGNED: when rows are set aside (longRows > 0, window > 0) the others are cut
+ * into runs of `window` of them -- counted among themselves, not by original row number -- placed so that every window but the
+ * first starts at a multiple of `window` in the new order.  A kernel whose workgroups own `window` consecutive ordered rows
+ * then owns exactly one window: its slice of x is one window wide and it writes whole lines of z (with oellOrder's windows a
+ * workgroup straddles two).  Measured on the north_star target: band columns +3 %, columns spread over
+ * +-window of the row -9 % -- hence a call of its own rather than the rule.  Identical to oellOrder when longRows <= 0 or
+ * window <= 0. */
+void oellOrderAligned(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,12 @@ spgpuStatus_t spgpuOellOrderDevice(spgpuHandle_t handle, __device int* rIdx, __d
                                    const __device int* srcRs, int rowsCount, int window, int longRows,
                                    __device void* work);
 
+/* The aligned form (oellOrderAligned, ell_conv.h): same arguments and scratch; the windows of the rows that are not set
+ * aside are runs of `window` of them, every one but the first starting at a multiple of `window` in the new order. */
+spgpuStatus_t spgpuOellOrderAlignedDevice(spgpuHandle_t handle, __device int* rIdx, __device int* dstRs,
+                                          const __device int* srcRs, int rowsCount, int window, int longRows,
+                                          __device void* work);
+
 /* Device counterpart of ellToOell (ell_conv.h; reference ell.c:161-202) with the two extra parameters of oellOrder:
  * order, then copy of the real entries (destination arrays zeroed by the caller).  Byte-identical to the host call
  * for window <= 0, longRows <= 0. */

@@ -185,8 +185,10 @@ spgpuCooToHdiaDevice = _decl("spgpuCooToHdiaDevice", i32, [Handle, ptr, ptr, ptr
 
 # ---- oell_device.h (new: rows ordered by length in HBM) + the host order (ell_conv.h) ----------------------------
 oellOrder = _decl("oellOrder", None, [ptr, ptr, ptr, i32, i32, i32])
+oellOrderAligned = _decl("oellOrderAligned", None, [ptr, ptr, ptr, i32, i32, i32])
 spgpuOellOrderWorkBytes = _decl("spgpuOellOrderWorkBytes", C.c_size_t, [i32])
 spgpuOellOrderDevice = _decl("spgpuOellOrderDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, ptr])
+spgpuOellOrderAlignedDevice = _decl("spgpuOellOrderAlignedDevice", i32, [Handle, ptr, ptr, ptr, i32, i32, i32, ptr])
 spgpuEllToOellDevice = _decl("spgpuEllToOellDevice", i32, [Handle, ptr, ptr, ptr, ptr, ptr, ptr, ptr, i32, i32, i32, i32, i32, i32, ptr])
 spgpuCooPermuteRowsDevice = _decl("spgpuCooPermuteRowsDevice", i32, [Handle, ptr, ptr, i32, ptr, i32, i32, ptr])
 

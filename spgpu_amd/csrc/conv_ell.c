@@ -82,7 +82,7 @@ static int oellKeyCompare(const void* pa, const void* pb)
     return a->descending ? -order : order;
 }
 
-void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows)
+static void oellOrderGeneral(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows, int aligned)
 {
     if (rowsCount <= 0)
         return;
@@ -101,13 +101,23 @@ void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int windo
         return;
     const long long longWindow = window > 0 ? (long long)window * SPGPU_OELL_LONG_WINDOW_FACTOR : 0;
     const unsigned longGroups = longRows > 0 ? (longWindow > 0 ? (unsigned)((rowsCount - 1) / longWindow) + 1u : 1u) : 0u;
+    /* aligned form (oellOrderAligned): the windows of the shorter rows are runs of `window` of THEM, cut so that every window
+     * but the first starts at a multiple of `window` in the new order */
+    aligned = aligned && window > 0 && longRows > 0;
+    long long longCount = 0, shorterSeen = 0;
+    if (aligned)
+        for (int r = 0; r < rowsCount; ++r)
+            longCount += srcRs[r] > longRows ? 1 : 0;
     for (int r = 0; r < rowsCount; ++r) {
         unsigned inClass;
         if (longRows > 0 && srcRs[r] > longRows) {
             inClass = longWindow > 0 ? (unsigned)(r / longWindow) : 0u;
             keys[r].group = inClass;
         } else {
-            inClass = window > 0 ? (unsigned)(r / window) : 0u;
+            if (aligned)
+                inClass = (unsigned)((longCount + shorterSeen++) / window - longCount / window);
+            else
+                inClass = window > 0 ? (unsigned)(r / window) : 0u;
             keys[r].group = longGroups + inClass;
         }
         keys[r].descending = inClass % 2 == 0;
@@ -120,6 +130,16 @@ void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int windo
         dstRs[i] = keys[i].len;
     }
     free(keys);
+}
+
+void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows)
+{
+    oellOrderGeneral(rIdx, dstRs, srcRs, rowsCount, window, longRows, 0);
+}
+
+void oellOrderAligned(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows)
+{
+    oellOrderGeneral(rIdx, dstRs, srcRs, rowsCount, window, longRows, 1);
 }
 
 /* ELL -> ordered ELL.  The reference sorts (length, row) pairs with a bottom-up merge sort whose

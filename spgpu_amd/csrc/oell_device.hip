@@ -19,6 +19,8 @@
 #include "spgpu/ell_conv.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 namespace spgpu {
 
@@ -33,6 +35,12 @@ static unsigned gridOverOe(long long n)
     return (unsigned)(blocks < 1 ? 1 : (blocks > 1048576 ? 1048576 : blocks));
 }
 
+/* 1 for a row that is set aside (longer than the threshold): scanned for the aligned form of the order */
+struct LongerThan {
+    int threshold;
+    __host__ __device__ int operator()(int len) const { return len > threshold ? 1 : 0; }
+};
+
 static hipError_t orderTempBytes(size_t n, size_t* bytes)
 {
     size_t keysBytes = 0, pairsBytes = 0;
@@ -43,19 +51,31 @@ static hipError_t orderTempBytes(size_t n, size_t* bytes)
                                     (unsigned*)nullptr, n);
     if (err != hipSuccess)
         return err;
-    *bytes = alignUpOe(keysBytes > pairsBytes ? keysBytes : pairsBytes, 256);
+    size_t scanBytes = 0;
+    err = rocprim::exclusive_scan(nullptr, scanBytes, rocprim::make_transform_iterator((const int*)nullptr, LongerThan{0}), (int*)nullptr, 0, n,
+                                  rocprim::plus<int>());
+    if (err != hipSuccess)
+        return err;
+    size_t most = keysBytes > pairsBytes ? keysBytes : pairsBytes;
+    most = most > scanBytes ? most : scanBytes;
+    *bytes = alignUpOe(most, 256);
     return hipSuccess;
 }
 
 /* group number with the direction of the group in bit 0: (group << 1) | ascending */
-__device__ inline unsigned groupOfRow(int row, int len, int window, int longRows, unsigned longGroups)
+/* longBefore (aligned form only, else null): rows set aside among the rows before this one; longCount: all of them */
+__device__ inline unsigned groupOfRow(int row, int len, int window, int longRows, unsigned longGroups, const int* longBefore,
+                                      long long longCount)
 {
     unsigned inClass, group;
     if (longRows > 0 && len > longRows) {
         inClass = window > 0 ? (unsigned)((long long)row / ((long long)window * SPGPU_OELL_LONG_WINDOW_FACTOR)) : 0u;
         group = inClass;
     } else {
-        inClass = window > 0 ? (unsigned)row / (unsigned)window : 0u;
+        if (longBefore) /* runs of `window` of the shorter rows, every run but the first starting on a multiple of `window` */
+            inClass = (unsigned)((longCount + (row - longBefore[row])) / window - longCount / window);
+        else
+            inClass = window > 0 ? (unsigned)row / (unsigned)window : 0u;
         group = longGroups + inClass;
     }
     return (group << 1) | (inClass & 1u);
@@ -69,14 +89,16 @@ __global__ __launch_bounds__(kOeThreads) void lengthKeysKernel(LenKey* keys, con
 }
 
 __global__ __launch_bounds__(kOeThreads) void groupKeysKernel(unsigned* groups, unsigned* rowsOut, const LenKey* sorted,
-                                                              int rows, int window, int longRows, unsigned longGroups)
+                                                              int rows, int window, int longRows, unsigned longGroups,
+                                                              const int* longBefore, const int* srcRs)
 {
+    const long long longCount = longBefore ? (long long)longBefore[rows - 1] + (srcRs[rows - 1] > longRows ? 1 : 0) : 0;
     const long long stride = (long long)gridDim.x * kOeThreads;
     for (long long i = (long long)blockIdx.x * kOeThreads + threadIdx.x; i < rows; i += stride) {
         const LenKey key = sorted[i];
         const unsigned row = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFu);
         const unsigned len = 0xFFFFFFFFu - (unsigned)(key >> 32);
-        groups[i] = groupOfRow((int)row, (int)len, window, longRows, longGroups);
+        groups[i] = groupOfRow((int)row, (int)len, window, longRows, longGroups, longBefore, longCount);
         rowsOut[i] = row;
     }
 }
@@ -126,7 +148,7 @@ __global__ __launch_bounds__(kOeThreads) void finishGroupedKernel(int* rIdx, int
 }
 
 static spgpuStatus_t orderRows(spgpuHandle_t handle, int* rIdx, int* dstRs, const int* srcRs, int rows, int window,
-                               int longRows, void* work)
+                               int longRows, void* work, bool aligned = false)
 {
     if (rows <= 0)
         return SPGPU_SUCCESS;
@@ -142,6 +164,9 @@ static spgpuStatus_t orderRows(spgpuHandle_t handle, int* rIdx, int* dstRs, cons
     LenKey* b = reinterpret_cast<LenKey*>(p);
     p += alignUpOe((size_t)rows * sizeof(LenKey), 256);
     void* temp = p;
+    p += tempBytes;
+    int* longBefore = reinterpret_cast<int*>(p); /* aligned form: rows * 4 bytes behind the sort's scratch */
+    aligned = aligned && window > 0 && longRows > 0;
 
     const bool whole = (window <= 0 || window >= rows) && longRows <= 0;
     if (whole && rows == 2) { /* ell.c:131-157 never merges exactly two rows */
@@ -161,8 +186,14 @@ static spgpuStatus_t orderRows(spgpuHandle_t handle, int* rIdx, int* dstRs, cons
     unsigned* rowIn = groupIn + rows;
     const long long longWindow = window > 0 ? (long long)window * SPGPU_OELL_LONG_WINDOW_FACTOR : 0;
     const unsigned longGroups = longRows > 0 ? (longWindow > 0 ? (unsigned)((rows - 1) / longWindow) + 1u : 1u) : 0u;
+    if (aligned) {
+        bytes = tempBytes;
+        if (rocprim::exclusive_scan(temp, bytes, rocprim::make_transform_iterator(srcRs, LongerThan{longRows}), longBefore, 0, (size_t)rows,
+                                    rocprim::plus<int>(), s) != hipSuccess)
+            return SPGPU_UNSPECIFIED;
+    }
     hipLaunchKernelGGL(groupKeysKernel, dim3(gridOverOe(rows)), dim3(kOeThreads), 0, s, groupIn, rowIn, (const LenKey*)b, rows,
-                       window, longRows, longGroups);
+                       window, longRows, longGroups, aligned ? (const int*)longBefore : (const int*)nullptr, srcRs);
     /* b is free again once groupKeysKernel has read it (same stream) */
     unsigned* groupOut = reinterpret_cast<unsigned*>(b);
     unsigned* rowOut = groupOut + rows;
@@ -227,13 +258,21 @@ size_t spgpuOellOrderWorkBytes(int rowsCount)
     size_t temp = 0;
     if (orderTempBytes((size_t)rowsCount, &temp) != hipSuccess)
         return 0;
-    return 2 * alignUpOe((size_t)rowsCount * sizeof(LenKey), 256) + temp;
+    return 2 * alignUpOe((size_t)rowsCount * sizeof(LenKey), 256) + temp + alignUpOe((size_t)rowsCount * sizeof(int), 256);
 }
 
 spgpuStatus_t spgpuOellOrderDevice(spgpuHandle_t handle, int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window,
                                    int longRows, void* work)
 {
     const spgpuStatus_t status = orderRows(handle, rIdx, dstRs, srcRs, rowsCount, window, longRows, work);
+    spgpuDebugCheck(handle, "oellOrder");
+    return status;
+}
+
+spgpuStatus_t spgpuOellOrderAlignedDevice(spgpuHandle_t handle, int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window,
+                                   int longRows, void* work)
+{
+    const spgpuStatus_t status = orderRows(handle, rIdx, dstRs, srcRs, rowsCount, window, longRows, work, true);
     spgpuDebugCheck(handle, "oellOrder");
     return status;
 }

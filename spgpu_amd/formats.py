@@ -136,17 +136,17 @@ def ell_to_oell(ell):
     return out, r_idx[:n_rows]
 
 
-def oell_order(row_lengths, window=0, long_rows=0):
-    """The host order call (ell_conv.h oellOrder): returns (rIdx, sorted lengths)."""
+def oell_order(row_lengths, window=0, long_rows=0, aligned=False):
+    """The host order call (ell_conv.h oellOrder, or oellOrderAligned): returns (rIdx, sorted lengths)."""
     rs = _i32(row_lengths)
     n = int(rs.size)
     r_idx, dst = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
-    capi.oellOrder(_p(r_idx), _p(dst), _p(rs if n else np.zeros(1, np.int32)), n, window, long_rows)
+    (capi.oellOrderAligned if aligned else capi.oellOrder)(_p(r_idx), _p(dst), _p(rs if n else np.zeros(1, np.int32)), n, window, long_rows)
     return r_idx[:n], dst[:n]
 
 
 def coo_to_ordered_hell_device(handle, n_rows, coo_rows, coo_cols, coo_vals, letter, hack_size=32, window=0, long_rows=0,
-                               coo_base=0, hell_base=0, order=True, r_idx_given=None):
+                               coo_base=0, hell_base=0, order=True, r_idx_given=None, aligned=False):
     """COO arrays in HBM (torch tensors) -> HELL in HBM with its rows ordered by length, all through the C ABI:
     spgpuCooRowLengthsDevice -> spgpuOellOrderDevice -> spgpuCooPermuteRowsDevice -> spgpuCooRowLengthsDevice ->
     spgpuHellPlanDevice -> spgpuCooToHellDevice.  order=False skips the ordering (plain HELL, rIdx None).
@@ -169,8 +169,8 @@ def coo_to_ordered_hell_device(handle, n_rows, coo_rows, coo_cols, coo_vals, let
         if r_idx_given is not None:      # experiments: an order computed elsewhere (any permutation of the rows)
             r_idx.copy_(r_idx_given)
         else:
-            ok(capi.spgpuOellOrderDevice(handle, _dp(r_idx), _dp(sorted_lengths), _dp(lengths), n_rows, window, long_rows,
-                                         _dp(order_work)))
+            order_call = capi.spgpuOellOrderAlignedDevice if aligned else capi.spgpuOellOrderDevice
+            ok(order_call(handle, _dp(r_idx), _dp(sorted_lengths), _dp(lengths), n_rows, window, long_rows, _dp(order_work)))
         inverse = torch.empty(max(n_rows, 1), dtype=torch.int32, device=dev)
         rows_in = torch.empty_like(coo_rows)
         ok(capi.spgpuCooPermuteRowsDevice(handle, _dp(rows_in), _dp(coo_rows), nnz, _dp(r_idx), n_rows, coo_base, _dp(inverse)))

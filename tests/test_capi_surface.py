@@ -10,7 +10,7 @@ from spgpu_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DECL = re.compile(r"^\s*(?:const\s+__device\s+)?(?:void|int|size_t|float|double\*?|long long|spgpuStatus_t|hipStream_t|hipFloatComplex|hipDoubleComplex)\s+"
-                  r"(spgpu\w+|computeEll\w+|cooTo\w+|coo2dia|computeHell\w+|ellTo\w+|getHdia\w+|computeHdia\w+|computeDia\w+|diaTo\w+|oellOrder)\s*\(", re.M)
+                  r"(spgpu\w+|computeEll\w+|cooTo\w+|coo2dia|computeHell\w+|ellTo\w+|getHdia\w+|computeHdia\w+|computeDia\w+|diaTo\w+|oellOrder\w*)\s*\(", re.M)
 
 
 def declared_functions():
@@ -28,7 +28,7 @@ def exported_symbols():
 
 def test_every_declared_function_is_exported_and_bound():
     declared = declared_functions()
-    assert len(declared) == 183, sorted(declared)  # C entry points; the C++ overloads of mmread.hpp are checked in test_mmread.py
+    assert len(declared) == 185, sorted(declared)  # C entry points; the C++ overloads of mmread.hpp are checked in test_mmread.py
     exported = exported_symbols()
     assert declared <= exported, sorted(declared - exported)
     assert declared <= set(capi.DECLARED), sorted(declared - set(capi.DECLARED))

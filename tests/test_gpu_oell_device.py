@@ -21,7 +21,7 @@ def _dp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _device_order(gpu, lengths, window, long_rows):
+def _device_order(gpu, lengths, window, long_rows, aligned=False):
     import torch
     from spgpu_amd import capi
     n = int(lengths.size)
@@ -30,9 +30,23 @@ def _device_order(gpu, lengths, window, long_rows):
     r_idx = torch.full((max(n, 1),), -7, dtype=torch.int32, device="cuda")
     dst = torch.full((max(n, 1),), -7, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    assert capi.spgpuOellOrderDevice(gpu, _dp(r_idx), _dp(dst), _dp(rs), n, window, long_rows, _dp(work)) == capi.SPGPU_SUCCESS
+    call = capi.spgpuOellOrderAlignedDevice if aligned else capi.spgpuOellOrderDevice
+    assert call(gpu, _dp(r_idx), _dp(dst), _dp(rs), n, window, long_rows, _dp(work)) == capi.SPGPU_SUCCESS
     torch.cuda.synchronize()
     return r_idx[:n].cpu().numpy(), dst[:n].cpu().numpy()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 33, 1000, 70001])
+@pytest.mark.parametrize("window,long_rows", [(0, 0), (32, 0), (0, 6), (512, 6), (64, 1), (2048, 20), (100000, 3)])
+def test_aligned_order_equals_host_order(gpu, n, window, long_rows):
+    """spgpuOellOrderAlignedDevice against the host oellOrderAligned (tests/test_oell_order.py pins that to its definition)."""
+    from spgpu_amd import formats
+    rng = np.random.default_rng(n + 13 * window + long_rows)
+    lengths = np.minimum(rng.zipf(1.6, size=n), 60).astype(np.int32)
+    want_idx, want_len = formats.oell_order(lengths, window, long_rows, aligned=True)
+    got_idx, got_len = _device_order(gpu, lengths, window, long_rows, aligned=True)
+    assert got_idx.tobytes() == want_idx.tobytes()
+    assert got_len.tobytes() == want_len.tobytes()
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 3, 33, 1000, 70001])

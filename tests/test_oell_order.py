@@ -38,6 +38,56 @@ def test_order_matches_its_definition(n, window, long_rows):
     assert sorted(r_idx.tolist()) == list(range(n))
 
 
+def brute_aligned_order(lengths, window, long_rows):
+    """oellOrderAligned's definition: the long rows as in oellOrder; the others, in their original order, fill the positions
+    behind them, and the windows are the runs of positions between multiples of `window`."""
+    lengths = np.asarray(lengths)
+    n = lengths.size
+    if window <= 0 or long_rows <= 0:
+        return brute_order(lengths, window, long_rows)
+    longs = [r for r in range(n) if lengths[r] > long_rows]
+    shorts = [r for r in range(n) if lengths[r] <= long_rows]
+    out = []
+    w = 32 * window
+    for g in range((n + w - 1) // w):
+        members = [r for r in longs if r // w == g]
+        out += sorted(members, key=(lambda r: (-lengths[r], -r)) if g % 2 == 0 else (lambda r: (lengths[r], r)))
+    P = len(longs)
+    first_window = P // window
+    position = P
+    while position < n:
+        end = min(n, (position // window + 1) * window)
+        members = shorts[position - P:end - P]
+        g = position // window - first_window
+        out += sorted(members, key=(lambda r: (-lengths[r], -r)) if g % 2 == 0 else (lambda r: (lengths[r], r)))
+        position = end
+    return np.array(out, np.int32)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 31, 32, 33, 257, 1000, 5003])
+@pytest.mark.parametrize("window,long_rows", [(0, 0), (8, 0), (0, 5), (16, 5), (2, 3), (100, 12), (64, 1), (64, 39), (64, 40)])
+def test_aligned_order_matches_its_definition(n, window, long_rows):
+    """oellOrderAligned: equal to oellOrder without a window or without rows set aside; otherwise every window of the shorter
+    rows but the first starts at a multiple of the window in the new order, holds `window` consecutive shorter rows, and is
+    sorted by (length, row) in alternating directions."""
+    rng = np.random.default_rng(n * 31 + window * 7 + long_rows)
+    lengths = np.minimum(rng.zipf(1.7, size=n), 40).astype(np.int32)
+    r_idx, dst = formats.oell_order(lengths, window, long_rows, aligned=True)
+    if window <= 0 or long_rows <= 0:
+        plain, _ = formats.oell_order(lengths, window, long_rows)
+        assert r_idx.tolist() == plain.tolist()
+    else:
+        assert r_idx.tolist() == brute_aligned_order(lengths, window, long_rows).tolist()
+        P = int((lengths > long_rows).sum())
+        assert (lengths[r_idx[:P]] > long_rows).all() and (lengths[r_idx[P:]] <= long_rows).all()
+        for start in range((P // window + 1) * window, n, window):      # the aligned windows: consecutive shorter rows
+            members = np.sort(r_idx[start:start + window])
+            shorter_between = np.flatnonzero(lengths[members[0]:members[-1] + 1] <= long_rows) + members[0]
+            assert members.tolist() == shorter_between.tolist()
+    assert dst.tolist() == lengths[r_idx].tolist()
+    assert sorted(r_idx.tolist()) == list(range(n))
+
+
 @pytest.mark.skipif(not O.reference_available(), reason="oracle/_ref is built in the build container only")
 @pytest.mark.parametrize("n", list(range(1, 40)) + [100, 257, 1024, 4099])
 def test_one_window_is_the_reference_order(n):

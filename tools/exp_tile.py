@@ -9,8 +9,8 @@ Environment: EXP_FORMS = comma list of  auto | gather | strips | tileN (x-tile s
 rows, workgroup shape N) | raggedg (the same with plain gathers); a suffix xR (ragged0x4) runs it with R consecutive row
 blocks per XCD.  EXP_PATTERNS = near,band,random (power-law) or near2048,near512,window,banded (uniform);
 EXP_ORDERS = window:longRows pairs (2048:256,...); EXP_ONLY_WINDOWED=1 skips the plain and globally sorted layouts;
-EXP_WINDOWS_FOR_ALL=1 runs the windowed orders on scattered columns too; EXP_ALIGNED=1 orders the rows on the host
-with windows counted among the short rows (one window = one workgroup; measured slower, DESIGN.md section 3.1);
+EXP_WINDOWS_FOR_ALL=1 runs the windowed orders on scattered columns too; EXP_ALIGNED=1 orders the rows with spgpuOellOrderAlignedDevice
+(windows counted among the short rows: one window = one workgroup; DESIGN.md section 3.1);
 EXP_DROP_RIDX=1 runs the ordered matrix without its row order (timing only).  SPGPU_* knobs pass through.
 """
 import ctypes as C
@@ -167,12 +167,13 @@ if "powerlaw" in cases:
         if os.environ.get("EXP_ONLY_WINDOWED"):
             orders = orders[2:]
         for name, order in orders:
-            given = None
-            if os.environ.get("EXP_ALIGNED") and order and order[0] > 0:
-                given = torch.from_numpy(aligned_order(lengths, *order)).cuda()
+            aligned = bool(os.environ.get("EXP_ALIGNED") and order and order[0] > 0)
+            if aligned:
                 name += " ALIGNED"
             h = formats.coo_to_ordered_hell_device(handle, n, rows_t, cols_t, vals_t, letter, 32, *(order or (0, 0)),
-                                                   order=order is not None, r_idx_given=given)
+                                                   order=order is not None, aligned=aligned)
+            if aligned and os.environ.get("EXP_ALIGNED") == "check":    # the device order against this file's numpy statement of it
+                assert h["rIdx"].cpu().numpy().tolist() == aligned_order(lengths, *order).tolist()
             forms = ["gather"] if ((pattern == "random" and not os.environ.get("EXP_WINDOWS_FOR_ALL")) or order is None or order == (0, 0)) else os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(",")
             run(h, f"power-law {pattern}, {name}", forms)
             del h
