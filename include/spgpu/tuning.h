@@ -17,6 +17,13 @@
  *   SPGPU_HDIA_BLOCK     HDIA workgroup size 256 / 512 (default) / 1024
  *   SPGPU_HDIA_NARROW    1: one row per lane even when 16-byte accesses are possible
  *   SPGPU_XCD_ORDER      HDIA: 0 hardware workgroup order (default), n: XCD-contiguous runs of n
+ *   SPGPU_DEEP_CAP       ELL/HELL SpMV with a row order: a 32-row sub-group deeper than this many columns (default 256) hands
+ *                        columns to the deep kernels (the deep list below); SPGPU_DEEP_SPLIT=1 / 0 forces that on without a
+ *                        row order / off with one
+ *   SPGPU_DEEP_KEEP      of a 32-row sub-group deeper than SPGPU_DEEP_CAP, the columns the main kernel walks itself (default 64;
+ *                        -1 or >= the cap: all of the first SPGPU_DEEP_CAP).  The rest are items of 64 columns for the deep
+ *                        kernels.  With 256 the workgroups that hold the set-aside long rows -- 64 sub-groups of 256 columns
+ *                        each -- lived as long as the whole launch (profiles/r03_ragged_workgroup_trace.txt)
  *   SPGPU_RAGGED_SPLIT   ELL/HELL SpMV with a row order: columns per chunk of a 32-row sub-group that several wavefronts share
  *                        (unset: about 96; 0: never cut; rounded up to what LDS can park; csrc/ragged_spmv.hip.h, SPLIT)
  *   SPGPU_SPMM_VARIANT   SpMM kernel shape (0 = default, see csrc/hell_spmm.hip)

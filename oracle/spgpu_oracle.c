@@ -646,10 +646,11 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
             if ((rS ? rS[r] : maxNnz) > depth) depth = rS ? rS[r] : maxNnz;                                   \
         return depth > deepCap ? depth : 0;                                                                   \
     }                                                                                                         \
-    static int P##_walked(const int* rS, int maxNnz, int rows, int i, int deepCap)                            \
+    /* deepKeep <= deepCap: of a deep sub-group the main kernel walks the first deepKeep columns only, the rest are the deep kernels' */  \
+    static int P##_walked_keep(const int* rS, int maxNnz, int rows, int i, int deepCap, int deepKeep)         \
     {                                                                                                         \
         const int l = rS ? rS[i] : maxNnz;                                                                    \
-        return (P##_deep_group(rS, maxNnz, rows, i, deepCap) && l > deepCap) ? deepCap : l;                   \
+        return (P##_deep_group(rS, maxNnz, rows, i, deepCap) && l > deepKeep) ? deepKeep : l;                 \
     }                                                                                                         \
     /* mainChunk > 0 (the queue kernel for ordered rows, csrc/ragged_spmv.hip.h SPLIT): a 32-row sub-group whose walked */  \
     /* depth exceeds mainChunk is cut into chunks of mainChunk columns; a chunk's `phases` phase sums (by k mod phases, */   \
@@ -659,13 +660,13 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                             const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \
                             const int* rIdx, int rows, const T* x, T beta, int baseIndex, int groupRows,      \
                             int rowsPerLane, int step, int tailLanes, int phases, int deepCap, int deepPhases,\
-                            int deepChunk, int mainChunk)                                                     \
+                            int deepChunk, int mainChunk, int deepKeep)                                       \
     {                                                                                                         \
         for (int g0 = 0; g0 < rows; g0 += groupRows) {                                                        \
             const int gEnd = g0 + groupRows < rows ? g0 + groupRows : rows;                                   \
             int longest = 0;                                                                                  \
             for (int i = g0; i < gEnd; ++i) {                                                                 \
-                const int l = P##_walked(rS, maxNnz, rows, i, deepCap);                                       \
+                const int l = P##_walked_keep(rS, maxNnz, rows, i, deepCap, deepKeep);                                       \
                 if (l > longest) longest = l;                                                                 \
             }                                                                                                 \
             int tailFrom = longest;                                                                           \
@@ -674,7 +675,7 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                 for (int s0 = g0; s0 < gEnd; s0 += rowsPerLane) {                                             \
                     int laneLongest = 0;                                                                      \
                     for (int i = s0; i < s0 + rowsPerLane && i < gEnd; ++i) {                                 \
-                        const int l = P##_walked(rS, maxNnz, rows, i, deepCap);                               \
+                        const int l = P##_walked_keep(rS, maxNnz, rows, i, deepCap, deepKeep);                               \
                         if (l > laneLongest) laneLongest = l;                                                 \
                     }                                                                                         \
                     busy += kBase < laneLongest;                                                              \
@@ -683,7 +684,7 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
             }                                                                                                 \
             for (int i = g0; i < gEnd; ++i) {                                                                 \
                 const int fullLen = rS ? rS[i] : maxNnz;                                                      \
-                const int len = P##_walked(rS, maxNnz, rows, i, deepCap);                                     \
+                const int len = P##_walked_keep(rS, maxNnz, rows, i, deepCap, deepKeep);                                     \
                 const size_t slot0 = hackOffsets ? (size_t)hackOffsets[i / hackSize] + (size_t)(i % hackSize) : (size_t)i; \
                 const size_t vs = hackOffsets ? (size_t)hackSize : (size_t)cMPitch;                           \
                 const size_t is = hackOffsets ? (size_t)hackSize : (size_t)rPPitch;                           \
@@ -707,7 +708,7 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                 if (mainChunk > 0) {                                                                          \
                     int walkedDepth = 0; /* of row i's 32-row sub-group */                                     \
                     for (int r = i / 32 * 32; r < i / 32 * 32 + 32 && r < rows; ++r) {                         \
-                        const int l = P##_walked(rS, maxNnz, rows, r, deepCap);                               \
+                        const int l = P##_walked_keep(rS, maxNnz, rows, r, deepCap, deepKeep);                               \
                         if (l > walkedDepth) walkedDepth = l;                                                 \
                     }                                                                                         \
                     if (walkedDepth > mainChunk) {                                                            \
@@ -728,13 +729,13 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                     /* (each over ascending k) are combined pairwise; the chunk sums join the slab kernel's sum in */ \
                     /* chunk order */                                                                         \
                     /* chunk order; a row shorter than its sub-group adds the later chunks' +0 as the kernel does */ \
-                    for (int c0 = deepCap; c0 < subDepth; c0 += deepChunk) {                                  \
+                    for (int c0 = deepKeep; c0 < subDepth; c0 += deepChunk) {                                  \
                         T part[ORC_MAX_PHASES];                                                               \
                         for (int p = 0; p < deepPhases; ++p) part[p] = P##_zero();                            \
                         for (int k = c0; k < fullLen && k < c0 + deepChunk; ++k) {                            \
                             const int col = rP[slot0 + (size_t)k * is] - baseIndex;                           \
                             if (col >= 0)                                                                     \
-                                part[(k - deepCap) % deepPhases] = P##_fma(cM[slot0 + (size_t)k * vs], x[col], part[(k - deepCap) % deepPhases]); \
+                                part[(k - deepKeep) % deepPhases] = P##_fma(cM[slot0 + (size_t)k * vs], x[col], part[(k - deepKeep) % deepPhases]); \
                         }                                                                                     \
                         total = P##_add(total, P##_combine(part, deepPhases));                                \
                     }                                                                                         \
@@ -750,7 +751,7 @@ ORC_DEFINE_TYPE(z, orc_cdouble, double)
                             int deepChunk)                                                                    \
     {                                                                                                         \
         orc_##P##spmv_split(z, y, alpha, cM, rP, hackSize, hackOffsets, cMPitch, rPPitch, rS, maxNnz, rIdx, rows, x, beta, \
-                            baseIndex, groupRows, rowsPerLane, step, tailLanes, phases, deepCap, deepPhases, deepChunk, 0); \
+                            baseIndex, groupRows, rowsPerLane, step, tailLanes, phases, deepCap, deepPhases, deepChunk, 0, deepCap); \
     }                                                                                                         \
     void orc_##P##spmv_tail(T* z, const T* y, T alpha, const T* cM, const int* rP, int hackSize,             \
                             const int* hackOffsets, int cMPitch, int rPPitch, const int* rS, int maxNnz,      \

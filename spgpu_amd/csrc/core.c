@@ -295,6 +295,7 @@ void spgpuTuningReload(void)
     t.xTileShape = envInt("SPGPU_X_TILE_SHAPE", 0);
     t.deepSplit = envInt("SPGPU_DEEP_SPLIT", -1);
     t.deepCap = envInt("SPGPU_DEEP_CAP", 256);
+    t.deepKeep = envInt("SPGPU_DEEP_KEEP", 64);
     t.ragged = envInt("SPGPU_RAGGED", 1);
     t.raggedShape = envInt("SPGPU_RAGGED_SHAPE", 0);
     t.pipeGroups = envInt("SPGPU_PIPE_GROUPS", 0);

@@ -74,6 +74,7 @@ template <typename T> struct SlabArgs {
     long long tileSpanLimit; /* a sample group whose columns span at most this many counts as "local" (x-tile form) */
     /* DEEP kernels: 32-row sub-groups deeper than deepCap hand their columns >= deepCap to the deep kernels */
     int deepCap;
+    int deepKeep;                /* of a sub-group deeper than deepCap the main kernel walks the first deepKeep columns (<= deepCap); the rest are items */
     int deepChunk;               /* columns per item */
     int* deepHeader;             /* entries registered, items handed out (may exceed the capacities), finish ticket */
     SpgpuDeepEntry* deepEntries; /* [SPGPU_DEEP_ENTRIES] */
@@ -118,7 +119,7 @@ template <int POLICY, typename T> __device__ inline T loadX(const T* p)
  * the main kernel.  (The list is global: which entry a sub-group gets depends on scheduling, its sum does not.) */
 template <typename T> __device__ inline int deepRegister(const SlabArgs<T>& a, int row0, int depth)
 {
-    const int items = (depth - a.deepCap + a.deepChunk - 1) / a.deepChunk;
+    const int items = (depth - a.deepKeep + a.deepChunk - 1) / a.deepChunk;
     const int entry = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES], 1);
     if (entry >= SPGPU_DEEP_ENTRIES)
         return -1;
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
             laneLongest = 0;
 #pragma unroll
             for (int t = 0; t < RPL; ++t) {
-                len[t] = len[t] < a.deepCap ? len[t] : a.deepCap;
+                len[t] = len[t] < a.deepKeep ? len[t] : a.deepKeep;
                 laneLongest = len[t] > laneLongest ? len[t] : laneLongest;
             }
         }
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(kBlockThreads) void deepItemsKernel(const SlabArgs<
         const int chunk = item - entry.firstItem;
         if (chunk < 0 || chunk >= entry.items)
             continue;
-        const int kFirst = a.deepCap + chunk * CHUNK;
+        const int kFirst = a.deepKeep + chunk * CHUNK;
         const int kEnd = kFirst + CHUNK < entry.depth ? kFirst + CHUNK : entry.depth;
         const long long row0 = (long long)entry.row0 + (long long)sub * RPL;
         long long slab = 0;
@@ -920,7 +921,8 @@ __global__ __launch_bounds__(kWave) void formProbeKernel(const SlabArgs<T> a)
  * the results staged in LDS by destination (whole-line stores of z; 48 KiB left for the x tile) wins when the columns of a
  * window of rows fit that tile, 1 024 rows with a 64 KiB tile when they spread further (columns +-2 048 of the row: 2 048
  * rows would need 64 KiB and more).  192 sampled rows answer: 4 = three quarters of them keep within 1 024 of the
- * diagonal, 5 = they do not.  Launched by AUTO when it has no answer for the matrix, and again every 64th call.
+ * diagonal, 5 = they do not; 6 = whatever the columns do, the kernel's 2 048-row blocks are the windows of the order.
+ * Launched by AUTO when it has no answer for the matrix, and again every 64th call.
  */
 template <bool IS_HELL>
 __global__ __launch_bounds__(kWave) void orderedProbeKernel(const int* rP, const int* rS, const int* hackOffsets, const int* rIdx, int hackSize,
@@ -951,8 +953,22 @@ __global__ __launch_bounds__(kWave) void orderedProbeKernel(const int* rP, const
         near += laneXor(near, m);
         seen += laneXor(seen, m);
     }
+    /* Are the kernel's 2 048-row blocks the windows of the order (spgpuOellOrderAlignedDevice)?  64 rows spread over each of
+     * three blocks: the rows of ONE window come from a stretch of the original numbering little longer than the window, the
+     * rows of a block that straddles two windows from twice that.  Then the 2 048-row shape serves wide columns too: its tile
+     * holds the one window +- 2 048 such a block touches, and the block's results are whole lines of z. */
+    int blocksAreWindows = 0, blocksSeen = 0;
+    for (int q = 1; q <= 3; ++q) {
+        const long long block0 = ((long long)rows * q / 4) / 2048 * 2048;
+        if (block0 + 2048 > rows)
+            continue;
+        const int dest = rIdx[block0 + lane * 32 + (lane & 31)];
+        const int low = waveMin(dest), high = waveMax(dest);
+        blocksSeen += 1;
+        blocksAreWindows += high - low < 2048 + 512 ? 1 : 0;
+    }
     if (lane == 0)
-        *answer = (seen > 0 && 4 * near >= 3 * seen) ? 4 : 5;
+        *answer = (blocksSeen > 0 && blocksAreWindows == blocksSeen) ? 6 : (seen > 0 && 4 * near >= 3 * seen) ? 4 : 5;
 }
 
 /*
@@ -1254,6 +1270,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     bool deepSplit = (tune->deepSplit >= 0 ? tune->deepSplit != 0 : a.rIdx != nullptr) && wideOk &&
                      (variant == 21 || variant == 22);
     a.deepCap = tune->deepCap > 0 ? tune->deepCap : 256;
+    a.deepKeep = tune->deepKeep >= 0 && tune->deepKeep < a.deepCap ? tune->deepKeep : a.deepCap;
     a.xcdRun = tune->xcdOrder;
     a.deepChunk = kDeepChunk;
     a.deepHeader = nullptr;
@@ -1317,7 +1334,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             if (said == 0 || calls % 64 == 0)
                 hipLaunchKernelGGL((orderedProbeKernel<IS_HELL>), dim3(1), dim3(kWave), 0, stream, a.rP, a.rS, a.hackOffsets, a.rIdx, a.hackSize,
                                    a.idxStride, a.maxNnz, a.rows, a.baseIndex, seen + 3);
-            shape = said == 4 ? 4 : 0;
+            shape = said == 4 || said == 6 ? 4 : 0; /* 6: the blocks are the windows of an aligned order */
         }
         const bool deepKernels = launchRagged<T, WIDE, IS_HELL, true>(stream, a, shape, form != SPGPU_SPMV_FORM_GATHER);
         if (deepPossible && deepKernels)

@@ -139,14 +139,14 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
             slot = __shfl(slot, lane & 32, kWave);
         }
         if (i < ROWS) {
-            const int walked = (slot >= 0 && myLen[j] > a.deepCap) ? a.deepCap : myLen[j];
+            const int walked = (slot >= 0 && myLen[j] > a.deepKeep) ? a.deepKeep : myLen[j];
             lens[i] = (unsigned short)(walked < 0xFFFF ? walked : 0xFFFF);
             if constexpr (!ZSTAGE)
                 dests[i] = myDest[j];
             if (i % RPL == 0)
                 bases[i / RPL] = myBase[j];
             if ((lane & 31) == 0) {
-                depths[i >> 5] = (slot >= 0 && depth > a.deepCap) ? a.deepCap : depth;
+                depths[i >> 5] = slot >= 0 ? a.deepKeep : depth;
                 deepSlots[i >> 5] = slot;
             }
         }

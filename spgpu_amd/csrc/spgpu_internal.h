@@ -104,6 +104,7 @@ typedef struct SpgpuTuning {
     int xTileShape;  /* 0 */
     int deepSplit;   /* -1: when rIdx is given */
     int deepCap;     /* 256 */
+    int deepKeep;    /* 64: columns of a sub-group deeper than deepCap that stay in the main kernel (-1 or >= deepCap: deepCap) */
     int ragged;      /* 1: the queue-driven kernel where the deep split is on */
     int raggedShape; /* 0 */
     int pipeGroups;  /* 0: one workgroup per CU (tests: fewer, so that small matrices run several blocks per workgroup) */

@@ -424,9 +424,10 @@ for _L, _T in SCALAR.items():
     _f = getattr(orc, f"orc_{_LOW[_L]}spmv_split")
     _f.restype = None
     _f.argtypes = [ptr, ptr, _T, ptr, ptr, i32, ptr, i32, i32, ptr, i32, ptr, i32, ptr, _T, i32, i32, i32, i32, i32, i32,
-                   i32, i32, i32, i32]
+                   i32, i32, i32, i32, i32]
 
 DEEP_CAP = 256   # SPGPU_DEEP_CAP default
+DEEP_KEEP = 64   # SPGPU_DEEP_KEEP default: columns of a deep sub-group the main kernel walks itself
 SHARE_CHUNK = 48  # columns per item of shareSpmvKernel (every type)
 # deepItemsKernel (csrc/ellpack_spmv.hip launchDeep): phases = 64 / (32 / rows per lane); items of 64 columns
 DEEP_SHAPE = {"S": dict(deep_phases=8, deep_chunk=64), "D": dict(deep_phases=4, deep_chunk=64),
@@ -434,7 +435,7 @@ DEEP_SHAPE = {"S": dict(deep_phases=8, deep_chunk=64), "D": dict(deep_phases=4, 
 
 
 def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_rows=128, rows_per_lane=2, step=8,
-              tail_lanes=16, phases=1, deep_cap=0, deep_phases=1, deep_chunk=1, main_chunk=0):
+              tail_lanes=16, phases=1, deep_cap=0, deep_phases=1, deep_chunk=1, main_chunk=0, deep_keep=None):
     """HELL (dict has hack_offsets) or ELL SpMV in the summation order of the tail-mode slab kernel; deep_cap > 0: with
     the deep split (32-row sub-groups deeper than deep_cap finished by deepSpmvKernel)."""
     L = mat["letter"]
@@ -448,7 +449,7 @@ def spmv_tail(mat, x, y, alpha, beta, r_idx=None, with_row_sizes=True, group_row
         _p(mat["hack_offsets"]) if is_hell else None, 0 if is_hell else mat["pitch"], 0 if is_hell else mat["pitch"],
         _p(rs), 0 if is_hell else mat["max_row"], _p(ri), mat["rows"], _p(np.ascontiguousarray(x, NP_DTYPE[L])),
         scalar(L, beta), mat["base"], group_rows, rows_per_lane, step, tail_lanes, phases, deep_cap, deep_phases, deep_chunk,
-        main_chunk)
+        main_chunk, deep_cap if deep_keep is None or deep_keep < 0 or deep_keep > deep_cap else deep_keep)
     return z
 
 
@@ -464,11 +465,15 @@ def ragged_split(letter, step, deep_cap, asked=-1):
     return max(want, need)
 
 
-def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0, split=-1):
+def slab_shape(letter, form="gather", tile_shape=0, deep_cap=0, split=-1, deep_keep=None):
     """spmv_tail parameters of the kernel the library runs for (type, x form, deep split): csrc/ellpack_spmv.hip
     launchSlabFamily / launchTiled.  None for the shapes without a tail (complex fp64 outside the deep split: 2 phases)."""
     rpl = {"S": 4, "D": 2, "C": 2, "Z": 1}[letter]
-    deep = dict(deep_cap=deep_cap, **DEEP_SHAPE[letter]) if deep_cap > 0 else {}
+    import os
+    if deep_keep is None:   # what the library reads (SPGPU_DEEP_KEEP, csrc/core.c), clamped to the cap as it does
+        deep_keep = int(os.environ.get("SPGPU_DEEP_KEEP", DEEP_KEEP))
+    deep_keep = deep_keep if 0 <= deep_keep < deep_cap else deep_cap
+    deep = dict(deep_cap=deep_cap, deep_keep=deep_keep, **DEEP_SHAPE[letter]) if deep_cap > 0 else {}
     if form == "share":    # shareSpmvKernel (csrc/share_spmv.hip.h): (sub-group, chunk) items, 48 columns per chunk, the
         phases = 2 * rpl   # chunk sums of a sub-group added in chunk order
         return dict(group_rows=32, rows_per_lane=rpl, step=phases * (2 if rpl >= 4 else 3), tail_lanes=0, phases=phases,

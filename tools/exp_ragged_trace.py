@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box experiment (needs the -DSPGPU_TRACE_BLOCKS build, SPGPU_LIB=...): the queue kernel (raggedSpmvKernel) on the ordered
 power-law matrix: start, tile-in-place and end of every workgroup -> how much of the launch is prologue, stream, ramp and tail.
-  python tools/exp_ragged_trace.py [rows] [window:long] [powerlaw|even] ; EXP_PATTERN=near|band ; SPGPU_RAGGED_SHAPE=0|4|5"""
+  python tools/exp_ragged_trace.py [rows] [window:long] [powerlaw|even] ; EXP_PATTERN=near|band ; SPGPU_RAGGED_SHAPE=0|4|5 ; EXP_ALIGNED=1: spgpuOellOrderAlignedDevice"""
 import ctypes as C
 import os
 import sys
@@ -25,7 +25,7 @@ if case == "powerlaw":
 else:
     lengths = np.random.default_rng(1).integers(24, 41, size=n).astype(np.int32)
 coo = synth.ragged_coo_on_device(lengths, n, os.environ.get("EXP_PATTERN", "band"), 2048, "D", seed=5)
-h = formats.coo_to_ordered_hell_device(handle, n, *coo, "D", 32, window, long_rows)
+h = formats.coo_to_ordered_hell_device(handle, n, *coo, "D", 32, window, long_rows, aligned=bool(os.environ.get("EXP_ALIGNED")))
 x = synth.device_vector(n, "D", 3)
 z = torch.zeros(n, dtype=torch.float64, device="cuda")
 groups = (n + rows_per_group - 1) // rows_per_group
@@ -48,7 +48,7 @@ start, end, tiled = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t
 span = end.max()
 life, prologue = end - start, tiled - start
 slots = 512.0
-print(f"{case} {os.environ.get('EXP_PATTERN', 'band')} shape {shape}: {groups} workgroups, main kernel span {span:.1f} us")
+print(f"{case} {os.environ.get('EXP_PATTERN', 'band')}{' ALIGNED' if os.environ.get('EXP_ALIGNED') else ''} shape {shape}: {groups} workgroups, main kernel span {span:.1f} us")
 print(f"  workgroup life: min {life.min():.1f} median {np.median(life):.1f} p90 {np.percentile(life, 90):.1f} max {life.max():.1f} us;"
       f" prologue (start -> tile in place): median {np.median(prologue):.1f} p90 {np.percentile(prologue, 90):.1f} us")
 print(f"  occupancy of the {slots:.0f} workgroup slots over the span: {life.sum() / (slots * span):.3f} resident,"

@@ -158,7 +158,7 @@ def aligned_order(lengths, window, long_rows):
 if "powerlaw" in cases:
     lengths = synth.power_law_lengths(n, mean=32.0, max_len=int(os.environ.get("EXP_MAXLEN", "2048")), seed=5)   # EXP_MAXLEN: where do the long rows' costs start?
     for pattern in os.environ.get("EXP_PATTERNS", "near,random").split(","):
-        rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 2048, letter, seed=5)
+        rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, int(os.environ.get("EXP_NEAR", "2048")), letter, seed=5)   # EXP_NEAR: half-width of the "near" pattern
         torch.cuda.synchronize()
         orders = [("plain", None), ("sorted all", (0, 0))]
         if pattern in ("near", "band") or os.environ.get("EXP_WINDOWS_FOR_ALL"):
