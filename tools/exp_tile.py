@@ -83,6 +83,8 @@ def run(h, label, forms):
                                          None if os.environ.get("EXP_DROP_RIDX") else p(r_idx), 32, rows, p(x), zero, 0)
     for full in forms:
         name = full
+        full, _, keep = full.partition("%")         # "auto%32": SPGPU_DEEP_KEEP for this run (same matrix, same process)
+        os.environ["SPGPU_DEEP_KEEP"] = keep or os.environ.get("EXP_DEEP_KEEP", "64")
         full, _, split = full.partition("@")        # "ragged0@0": sub-groups never cut; "ragged4@48": chunks of 48 columns
         os.environ["SPGPU_RAGGED_SPLIT"] = split or "-1"
         form, _, xcd = full.partition("x")          # "ragged0x4": shape 0 with runs of 4 row blocks per XCD
