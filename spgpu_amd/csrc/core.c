@@ -16,7 +16,7 @@
 /* ---- deep lists of the ELL/HELL SpMV (spgpu_internal.h): one per stream ---- */
 #define DEEP_HEAD_BYTES (SPGPU_DEEP_HEAD_INTS * sizeof(int))
 #define DEEP_ENTRY_BYTES ((size_t)SPGPU_DEEP_ENTRIES * sizeof(SpgpuDeepEntry))
-#define DEEP_ITEM_ENTRY_BYTES ((size_t)SPGPU_DEEP_ITEMS * sizeof(int))
+#define DEEP_ITEM_ENTRY_BYTES ((size_t)SPGPU_DEEP_ITEMS * sizeof(SpgpuDeepItem))
 #define DEEP_PARTIAL_BYTES ((size_t)SPGPU_DEEP_ENTRIES * 32 * 16)
 #define DEEP_ITEM_SUM_BYTES ((size_t)SPGPU_DEEP_ITEMS * 32 * 16)
 
@@ -222,7 +222,7 @@ spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, SpgpuDeepList* list)
         return SPGPU_UNSUPPORTED;
     list->header = (int*)base;
     list->entries = (SpgpuDeepEntry*)(base + DEEP_HEAD_BYTES);
-    list->itemEntry = (int*)(base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES);
+    list->items = (SpgpuDeepItem*)(base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES);
     list->partials = base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES;
     list->itemSums = base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES + DEEP_PARTIAL_BYTES;
     return SPGPU_SUCCESS;

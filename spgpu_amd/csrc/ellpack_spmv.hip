@@ -78,7 +78,7 @@ template <typename T> struct SlabArgs {
     int deepChunk;               /* columns per item */
     int* deepHeader;             /* entries registered, items handed out (may exceed the capacities), finish ticket */
     SpgpuDeepEntry* deepEntries; /* [SPGPU_DEEP_ENTRIES] */
-    int* deepItemEntry;          /* [SPGPU_DEEP_ITEMS] */
+    SpgpuDeepItem* deepItems;    /* [SPGPU_DEEP_ITEMS] */
     T* deepPartials;             /* [SPGPU_DEEP_ENTRIES][32] row sums over the columns < deepCap */
     T* deepItemSums;             /* [SPGPU_DEEP_ITEMS][32] */
     int* deepOverflow;           /* pinned: calls that overflowed the list, and what the last of them asked for */
@@ -117,7 +117,7 @@ template <int POLICY, typename T> __device__ inline T loadX(const T* p)
 /* One lane registers a 32-row sub-group deeper than deepCap in the handle's deep list: an entry, and one item per
  * deepChunk columns beyond the cap.  Returns the entry, or -1 when the list is full -- the sub-group then stays with
  * the main kernel.  (The list is global: which entry a sub-group gets depends on scheduling, its sum does not.) */
-template <typename T> __device__ inline int deepRegister(const SlabArgs<T>& a, int row0, int depth)
+template <typename T> __device__ inline int deepRegister(const SlabArgs<T>& a, int row0, int depth, unsigned base)
 {
     const int items = (depth - a.deepKeep + a.deepChunk - 1) / a.deepChunk;
     const int entry = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES], 1);
@@ -126,10 +126,13 @@ template <typename T> __device__ inline int deepRegister(const SlabArgs<T>& a, i
     const int first = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_ITEMS], items);
     const bool fits = first + items <= SPGPU_DEEP_ITEMS;
     a.deepEntries[entry] = SpgpuDeepEntry{row0, depth, first, fits ? items : 0};
-    if (!fits)
+    if (!fits) {
+        if (first < SPGPU_DEEP_ITEMS) /* the slots from `first` on keep what an earlier call left: nobody may read them */
+            atomicMax(&a.deepHeader[SPGPU_DEEP_HEAD_CUT], SPGPU_DEEP_ITEMS - first);
         return -1;
+    }
     for (int c = 0; c < items; ++c)
-        a.deepItemEntry[first + c] = entry;
+        a.deepItems[first + c] = SpgpuDeepItem{row0, base, depth, c};
     return entry;
 }
 
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
         }
         int slot = -1;
         if (lane % SUB == 0 && subDepth > a.deepCap)
-            slot = deepRegister(a, (int)row0, subDepth);
+            slot = deepRegister(a, (int)row0, subDepth, (unsigned)slab);
         deepSlot = __shfl(slot, lane & ~(SUB - 1), kWave);
         if (deepSlot >= 0) {
             laneLongest = 0;
@@ -693,94 +696,103 @@ __global__ __launch_bounds__(kBlockThreads) void deepItemsKernel(const SlabArgs<
     static_assert(CHUNK % STEP == 0, "a chunk is a whole number of stages");
     constexpr int WAVES = kBlockThreads / kWave;
 
-    const int registered = a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES];
-    const int handedOut = a.deepHeader[SPGPU_DEEP_HEAD_ITEMS];
-    const int entries = registered < SPGPU_DEEP_ENTRIES ? registered : SPGPU_DEEP_ENTRIES;
-    const int items = handedOut < SPGPU_DEEP_ITEMS ? handedOut : SPGPU_DEEP_ITEMS;
     const int lane = threadIdx.x & (kWave - 1);
     const int sub = lane % LPC, phase = lane / LPC;
-
-    for (int item = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6); item < items; item += (int)gridDim.x * WAVES) {
-        /* items past a registration that did not fit carry whatever an earlier call left: check, do not trust */
-        const int e = a.deepItemEntry[item];
-        if (e < 0 || e >= entries)
-            continue;
-        const SpgpuDeepEntry entry = a.deepEntries[e];
-        const int chunk = item - entry.firstItem;
-        if (chunk < 0 || chunk >= entry.items)
-            continue;
-        const int kFirst = a.deepKeep + chunk * CHUNK;
-        const int kEnd = kFirst + CHUNK < entry.depth ? kFirst + CHUNK : entry.depth;
-        const long long row0 = (long long)entry.row0 + (long long)sub * RPL;
-        long long slab = 0;
+    /* Round trip 1: the header and the item's record together (the grid has a wavefront for every item the list can hold, and
+     * the record lies inside the array whatever the header says).  Round trip 2: the row lengths and ALL of the item's slab
+     * columns -- the addresses come from the record, and a column below the sub-group's depth exists in the arrays whether a
+     * given row reaches it or not (what lies there is never used: the test is k < len).  Round trips 3 and 4: the gathers of
+     * the two halves.  (Before: header, entry number, entry, lengths and hack offset, first half, gathers, second half, gathers.) */
+    const int item = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
+    const int handedOut = a.deepHeader[SPGPU_DEEP_HEAD_ITEMS];
+    const int cut = a.deepHeader[SPGPU_DEEP_HEAD_CUT];
+    const SpgpuDeepItem mine = item < SPGPU_DEEP_ITEMS ? a.deepItems[item] : SpgpuDeepItem{0, 0u, 0, 0};
+    const int fresh = SPGPU_DEEP_ITEMS - cut; /* items below this were written by this call */
+    const int items = handedOut < fresh ? handedOut : fresh;
+    if (item >= items)
+        return;
+    {
+        const int kFirst = a.deepKeep + mine.chunk * CHUNK;
+        const int kEnd = kFirst + CHUNK < mine.depth ? kFirst + CHUNK : mine.depth;
+        const long long row0 = (long long)mine.row0 + (long long)sub * RPL;
+        long long slab = (long long)mine.base + (long long)sub * RPL;
+        if constexpr (IS_HELL) {
+            if ((a.hackSize & 31) != 0 && row0 < a.rows) { /* the sub-group may straddle hacks: the lane's own hack (wavefront-uniform test) */
+                const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
+                const unsigned hack = r0 / hs;
+                slab = (long long)a.hackOffsets[hack] + (r0 - hack * hs);
+            }
+        }
         int len[RPL];
-        int laneLongest = 0;
 #pragma unroll
         for (int t = 0; t < RPL; ++t) {
             const long long r = row0 + t;
             len[t] = r < a.rows ? (a.rS ? a.rS[r] : a.maxNnz) : 0;
-            len[t] = len[t] < kEnd ? len[t] : kEnd;
-            laneLongest = len[t] > laneLongest ? len[t] : laneLongest;
         }
-        if (row0 < a.rows) {
-            if constexpr (IS_HELL) {
-                const unsigned r0 = (unsigned)row0, hs = (unsigned)a.hackSize;
-                const unsigned hack = r0 / hs;
-                slab = (long long)a.hackOffsets[hack] + (r0 - hack * hs);
-            } else {
-                slab = row0;
+        const bool rowsExist = row0 < a.rows; /* a strip beyond the last row: nothing of it is loaded */
+        /* how far this lane may load: the item's end -- except where the sub-group straddles hacks (hackSize not a multiple of
+         * 32): the lane's own hack may be shallower than the sub-group, so there its own rows' lengths bound the loads (and are
+         * waited for first) */
+        int loadEnd = kEnd;
+        if constexpr (IS_HELL) {
+            if ((a.hackSize & 31) != 0) {
+                int own = 0;
+#pragma unroll
+                for (int t = 0; t < RPL; ++t)
+                    own = len[t] > own ? len[t] : own;
+                loadEnd = own < kEnd ? own : kEnd;
             }
         }
         const T* __restrict__ vals = a.cM + slab;
         const int* __restrict__ idxs = a.rP + slab;
+        constexpr int STAGES = CHUNK / STEP;
+        Pack<T, RPL> v[STAGES][UNROLL];
+        Pack<int, RPL> c[STAGES][UNROLL];
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int k = kFirst + s * STEP + u * PH + phase;
+                if (k < loadEnd && rowsExist) {
+                    v[s][u] = loadPack<true, T, RPL>(vals + (long long)k * a.valStride);
+                    c[s][u] = loadPack<true, int, RPL>(idxs + (long long)k * a.idxStride);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t) {
+                        v[s][u].v[t] = zeroOf<T>();
+                        c[s][u].v[t] = a.baseIndex;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < RPL; ++t)
+            len[t] = len[t] < kEnd ? len[t] : kEnd;
         T sum[RPL];
 #pragma unroll
         for (int t = 0; t < RPL; ++t)
             sum[t] = zeroOf<T>();
-
-        struct Stage {
-            Pack<T, RPL> v[UNROLL];
-            Pack<int, RPL> c[UNROLL];
-        };
-        auto fetch = [&](int kBase, Stage& s) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int k = kBase + u * PH + phase;
-                if (k < laneLongest) {
-                    s.v[u] = loadPack<true, T, RPL>(vals + (long long)k * a.valStride);
-                    s.c[u] = loadPack<true, int, RPL>(idxs + (long long)k * a.idxStride);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < RPL; ++t) {
-                        s.v[u].v[t] = zeroOf<T>();
-                        s.c[u].v[t] = a.baseIndex;
-                    }
-                }
-            }
-        };
-        Stage cur, nxt;
-        fetch(kFirst, cur);
-        for (int kBase = kFirst; kBase < kEnd; kBase += STEP) {
+        for (int s = 0; s < STAGES; ++s) {
             T xv[UNROLL][RPL];
             bool use[UNROLL][RPL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
-                const int k = kBase + u * PH + phase;
+                const int k = kFirst + s * STEP + u * PH + phase;
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
-                    const int col = cur.c[u].v[t] - a.baseIndex;
+                    const int col = c[s][u].v[t] - a.baseIndex;
                     use[u][t] = k < len[t] && col >= 0;
                     xv[u][t] = a.x[use[u][t] ? col : 0];
                 }
             }
-            fetch(kBase + STEP, nxt); /* behind the gathers in vmcnt order: stays in flight while they are used */
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
                 for (int t = 0; t < RPL; ++t)
-                    sum[t] = pick(use[u][t], mulAdd(cur.v[u].v[t], xv[u][t], sum[t]), sum[t]);
+                    sum[t] = pick(use[u][t], mulAdd(v[s][u].v[t], xv[u][t], sum[t]), sum[t]);
             }
-            cur = nxt;
+            __builtin_amdgcn_sched_barrier(0); /* one half's gathers at a time */
         }
 #pragma unroll
         for (int m = LPC; m < kWave; m <<= 1) {
@@ -840,6 +852,7 @@ __global__ __launch_bounds__(kBlockThreads) void deepFinishKernel(const SlabArgs
             a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES] = 0;
             a.deepHeader[SPGPU_DEEP_HEAD_ITEMS] = 0;
             a.deepHeader[SPGPU_DEEP_HEAD_TICKET] = 0;
+            a.deepHeader[SPGPU_DEEP_HEAD_CUT] = 0;
         }
     }
 }
@@ -1167,7 +1180,7 @@ static void launchDeep(hipStream_t stream, const SlabArgs<T>& a)
 {
     constexpr int PH = kWave / (32 / RPL);
     constexpr int UNROLL = 32 / PH; /* 32 columns per stage, two stages per item */
-    hipLaunchKernelGGL((deepItemsKernel<T, RPL, IS_HELL, UNROLL, kDeepChunk>), dim3(2048), dim3(kBlockThreads), 0, stream, a);
+    hipLaunchKernelGGL((deepItemsKernel<T, RPL, IS_HELL, UNROLL, kDeepChunk>), dim3(SPGPU_DEEP_ITEMS / (kBlockThreads / kWave)), dim3(kBlockThreads), 0, stream, a);
     hipLaunchKernelGGL((deepFinishKernel<T>), dim3(256), dim3(kBlockThreads), 0, stream, a);
 }
 
@@ -1275,7 +1288,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     a.deepChunk = kDeepChunk;
     a.deepHeader = nullptr;
     a.deepEntries = nullptr;
-    a.deepItemEntry = nullptr;
+    a.deepItems = nullptr;
     a.deepPartials = nullptr;
     a.deepItemSums = nullptr;
     a.deepOverflow = spgpuDeepOverflowWords(handle);
@@ -1285,7 +1298,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         if (spgpuDeepScratch(handle, &list) == SPGPU_SUCCESS) {
             a.deepHeader = list.header;
             a.deepEntries = list.entries;
-            a.deepItemEntry = list.itemEntry;
+            a.deepItems = list.items;
             a.deepPartials = static_cast<T*>(list.partials);
             a.deepItemSums = static_cast<T*>(list.itemSums);
         } else {

@@ -135,7 +135,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         int slot = -1;
         if constexpr (DEEP) {
             if ((lane & 31) == 0 && depth > a.deepCap && i < ROWS)
-                slot = deepRegister(a, (int)(blockRow0 + i), depth);
+                slot = deepRegister(a, (int)(blockRow0 + i), depth, myBase[j]);
             slot = __shfl(slot, lane & 32, kWave);
         }
         if (i < ROWS) {

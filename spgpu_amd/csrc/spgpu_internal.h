@@ -63,13 +63,24 @@ typedef struct SpgpuDeepEntry {
     int firstItem; /* its items are firstItem .. firstItem + items - 1 */
     int items;     /* 0: the item list was full, the main kernel kept the whole sub-group */
 } SpgpuDeepEntry;
+/* What a wavefront of deepItemsKernel needs to know about its item, in one 16-byte load: no look-up of the entry (a dependent
+ * round trip) stands between the header and the item's first loads. */
+typedef struct SpgpuDeepItem {
+    int row0;      /* first row of the sub-group */
+    unsigned base; /* slot of row0's first entry in the slab arrays (hackOffsets[hack] + row0 % hackSize; row0 for ELL) */
+    int depth;     /* the sub-group's longest row */
+    int chunk;     /* this item: columns deepKeep + chunk * deepChunk ... */
+} SpgpuDeepItem;
 #define SPGPU_DEEP_ENTRIES 8192
 #define SPGPU_DEEP_ITEMS 20480
-enum { SPGPU_DEEP_HEAD_ENTRIES = 0, SPGPU_DEEP_HEAD_ITEMS = 1, SPGPU_DEEP_HEAD_TICKET = 2, SPGPU_DEEP_HEAD_INTS = 64 };
+/* HEAD_CUT: SPGPU_DEEP_ITEMS - (first item of the first registration whose items did not fit), or 0: the items below
+ * SPGPU_DEEP_ITEMS - HEAD_CUT were all written by THIS call (a registration that does not fit leaves its slots as an earlier call
+ * left them, and every later one starts behind it) */
+enum { SPGPU_DEEP_HEAD_ENTRIES = 0, SPGPU_DEEP_HEAD_ITEMS = 1, SPGPU_DEEP_HEAD_TICKET = 2, SPGPU_DEEP_HEAD_CUT = 3, SPGPU_DEEP_HEAD_INTS = 64 };
 typedef struct SpgpuDeepList {
     int* header;             /* [SPGPU_DEEP_HEAD_INTS]: entries registered, items handed out (both may exceed the capacity), finish ticket */
     SpgpuDeepEntry* entries; /* [SPGPU_DEEP_ENTRIES] */
-    int* itemEntry;          /* [SPGPU_DEEP_ITEMS] entry of every item */
+    SpgpuDeepItem* items;    /* [SPGPU_DEEP_ITEMS] */
     void* partials;          /* [SPGPU_DEEP_ENTRIES][32] x 16 bytes: row sums over the columns < deepCap */
     void* itemSums;          /* [SPGPU_DEEP_ITEMS][32] x 16 bytes */
 } SpgpuDeepList;
