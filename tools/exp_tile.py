@@ -165,10 +165,15 @@ if "powerlaw" in cases:
         orders = [("plain", None), ("sorted all", (0, 0))]
         if pattern in ("near", "band") or os.environ.get("EXP_WINDOWS_FOR_ALL"):
             pairs = [tuple(int(v) for v in item.split(":")) for item in os.environ.get("EXP_ORDERS", "2048:128,2048:256,4096:256,8192:256,16384:0").split(",")]
-            orders += [(f"sorted window {w} long>{t}", (w, t)) for w, t in pairs]
+            # "window:long" or "window:long:cap" (SPGPU_DEEP_CAP for the runs on that order; without it the environment's)
+            orders += [(f"sorted window {p[0]} long>{p[1]}" + (f" cap {p[2]}" if len(p) > 2 else ""), p) for p in pairs]
         if os.environ.get("EXP_ONLY_WINDOWED"):
             orders = orders[2:]
         for name, order in orders:
+            if order and len(order) > 2:
+                os.environ["SPGPU_DEEP_CAP"] = str(order[2])
+                DEEP_CAP = order[2]
+                order = order[:2]
             aligned = bool(os.environ.get("EXP_ALIGNED") and order and order[0] > 0)
             if aligned:
                 name += " ALIGNED"

@@ -1,15 +1,5 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-timeout -k 10 1100 python3 -m pytest tests -q -m gpu -x > gpurun_out/gpu_tests.log 2>&1; rc=$?
-tail -4 gpurun_out/gpu_tests.log
-[ $rc -eq 0 ] || exit 1
-timeout -k 10 900 python3 bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench_err.log || { tail -5 gpurun_out/bench_err.log; exit 1; }
-python3 - <<'PY'
-import json
-d=json.loads(open('/root/repo/gpurun_out/bench_line.json').read().strip().splitlines()[-1])
-print({k:d[k] for k in ['value','ms_per_step']}, d['roofline']['frac'])
-for k,v in d['target'].items(): print(k, v)
-print(d['spmm_1gpu']['ms_per_step'], d['spmm_1gpu']['roofline_frac'])
-PY
-python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+export EXP_ONLY_WINDOWED=1 EXP_PATTERNS=band,near EXP_ALIGNED=1 EXP_FORMS=auto
+EXP_ORDERS=2048:256:256,2048:320:320,2048:384:384,2048:512:512,2048:256:256 timeout -k 10 900 python3 tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep -E "^D |MISMATCH" || exit 1
