@@ -1,5 +1,9 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-export EXP_ONLY_WINDOWED=1 EXP_PATTERNS=band,near EXP_ALIGNED=1 EXP_FORMS=auto
-EXP_ORDERS=2048:256:256,2048:320:320,2048:384:384,2048:512:512,2048:256:256 timeout -k 10 900 python3 tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep -E "^D |MISMATCH" || exit 1
+export EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256 EXP_PATTERNS=band,near EXP_FORMS=auto,auto EXP_ALIGNED=1 SPGPU_LIB=/root/repo/spgpu_amd/lib_ab/libspgpu.so
+for ov in "" 1 2; do
+echo "== SPGPU_EXP_OVERLAP=$ov"
+if [ -n "$ov" ]; then export SPGPU_EXP_OVERLAP=$ov; fi
+timeout -k 10 300 python3 tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep -E "^D " | cut -c1-140 || exit 1
+done
