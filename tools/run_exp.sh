@@ -1,9 +1,8 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out
-export EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256 EXP_PATTERNS=band,near EXP_FORMS=auto,auto EXP_ALIGNED=1 SPGPU_LIB=/root/repo/spgpu_amd/lib_ab/libspgpu.so
-for ov in "" 1 2; do
-echo "== SPGPU_EXP_OVERLAP=$ov"
-if [ -n "$ov" ]; then export SPGPU_EXP_OVERLAP=$ov; fi
-timeout -k 10 300 python3 tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep -E "^D " | cut -c1-140 || exit 1
+export EXP_ONLY_WINDOWED=1 EXP_ORDERS=2048:256 EXP_PATTERNS=band,near EXP_FORMS=auto,auto EXP_ALIGNED=1
+for L in lib lib_f8 lib_f4 lib; do
+echo "== $L"
+SPGPU_LIB=/root/repo/spgpu_amd/$L/libspgpu.so timeout -k 10 300 python3 tools/exp_tile.py D 10000000 powerlaw 2>&1 | grep -E "^D " | cut -c1-140 || exit 1
 done
