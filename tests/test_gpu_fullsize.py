@@ -196,8 +196,10 @@ def test_full_size_hdia_512_cubed(gpu):
     assert torch.equal(za, zh)
 
 
-def test_full_size_power_law_ordered_on_the_device(gpu):
-    """The north_star target at full size: 10 M rows, power-law lengths (mean 32, max 2048), fp64, columns near the row.
+@pytest.mark.parametrize("aligned", [False, True])
+def test_full_size_power_law_ordered_on_the_device(gpu, aligned):
+    """(aligned: spgpuOellOrderAlignedDevice -- every window of the order is one 2 048-row block of the new numbering.)
+    The north_star target at full size: 10 M rows, power-law lengths (mean 32, max 2048), fp64, columns near the row.
     Ordered on the device (windows of 2048 rows, rows longer than 256 set aside), built through the COO route, run
     through rIdx: slots per nonzero <= 1.1 (plain: ~5), the order is a permutation that keeps windowed rows inside
     their window, three ordered windows equal the oracle in the kernel's order bit for bit, the ordered product equals the
@@ -210,13 +212,18 @@ def test_full_size_power_law_ordered_on_the_device(gpu):
     x = synth.device_vector(n, "D", 3)
     torch.cuda.synchronize()
     plain = formats.coo_to_ordered_hell_device(gpu, n, *coo, "D", 32, order=False)
-    ordered = formats.coo_to_ordered_hell_device(gpu, n, *coo, "D", 32, 2048, 256)
+    ordered = formats.coo_to_ordered_hell_device(gpu, n, *coo, "D", 32, 2048, 256, aligned=aligned)
     assert plain["slots"] / plain["nnz"] > 4.5 and ordered["slots"] / ordered["nnz"] <= 1.1
     r_idx = ordered["rIdx"].to(torch.int64)
     assert torch.equal(torch.sort(r_idx).values, torch.arange(n, device=r_idx.device))
     long_rows = int((torch.from_numpy(lengths) > 256).sum())
     moved = (r_idx[long_rows:] - torch.arange(n - long_rows, device=r_idx.device)).abs().max().item()
     assert moved < 2048 + long_rows          # a windowed row stays inside its window (shifted by the rows set aside)
+    if aligned:      # every 2 048-row block behind the set-aside rows holds 2 048 consecutive shorter rows of the original numbering
+        first_block = (long_rows // 2048 + 1) * 2048
+        blocks = r_idx[first_block:first_block + (n - first_block) // 2048 * 2048].view(-1, 2048)
+        spans = blocks.max(dim=1).values - blocks.min(dim=1).values
+        assert int(spans.max()) < 2048 + 512 and bool((blocks.min(dim=1).values[1:] > blocks.max(dim=1).values[:-1]).all())
     zp, zo = torch.zeros(n, dtype=torch.float64, device="cuda"), torch.zeros(n, dtype=torch.float64, device="cuda")
     for h, z in ((plain, zp), (ordered, zo)):
         capi.hellspmv["D"](gpu, _p(z), None, 1.0, _p(h["cM"]), _p(h["rP"]), 32, _p(h["hack_offsets"]), _p(h["rS"]), _p(h["rIdx"]), 32, n,
