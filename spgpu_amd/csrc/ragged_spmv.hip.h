@@ -24,6 +24,91 @@
  * Algorithmic bytes as for slabSpmvKernel, plus 4 per row for rIdx.
  */
 
+/* Cross-lane reductions of the prologue as DPP moves and readlanes (VALU / SALU only).  __shfl lowers to ds_bpermute, an LDS-queue
+ * instruction: harmless in an idle CU, but the workgroup beside this one is streaming through its LDS tile at that moment and
+ * every one of the ~70 dependent shuffles of the prologue waited its turn behind that traffic -- the prologue's compute-only
+ * stretches measured 2-5 us each (profiles/r03_ragged_workgroup_trace.txt). */
+template <int CTRL, int ROW_MASK> __device__ inline int dppMove(int keep, int v)
+{
+    return __builtin_amdgcn_update_dpp(keep, v, CTRL, ROW_MASK, 0xF, false);
+}
+struct MaxOf { static constexpr int identity = -0x7fffffff - 1; __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct MinOf { static constexpr int identity = 0x7fffffff; __device__ int operator()(int a, int b) const { return a < b ? a : b; } };
+struct SumOf { static constexpr int identity = 0; __device__ int operator()(int a, int b) const { return a + b; } };
+/* over the 16 lanes of each DPP row, result in every lane: neighbours, pairs, then the two mirrors */
+template <typename Op> __device__ inline int rowReduce(int v, Op op)
+{
+    v = op(v, dppMove<0xB1, 0xF>(v, v));  /* quad_perm [1,0,3,2] */
+    v = op(v, dppMove<0x4E, 0xF>(v, v));  /* quad_perm [2,3,0,1] */
+    v = op(v, dppMove<0x141, 0xF>(v, v)); /* row_half_mirror */
+    v = op(v, dppMove<0x140, 0xF>(v, v)); /* row_mirror */
+    return v;
+}
+/* over each 32-lane half of the wavefront, result in every lane of the half */
+template <typename Op> __device__ inline int halfReduce(int v, Op op)
+{
+    v = rowReduce(v, op);
+    v = op(v, dppMove<0x142, 0xA>(Op::identity, v)); /* row_bcast:15 into rows 1 and 3 */
+    const int low = __builtin_amdgcn_readlane(v, 31), high = __builtin_amdgcn_readlane(v, 63);
+    return (threadIdx.x & 32) ? high : low;
+}
+/* over the wavefront, as a scalar */
+template <typename Op> __device__ inline int waveReduce(int v, Op op)
+{
+    v = rowReduce(v, op);
+    v = op(v, dppMove<0x142, 0xA>(Op::identity, v)); /* row_bcast:15 into rows 1 and 3 */
+    v = op(v, dppMove<0x143, 0xC>(Op::identity, v)); /* row_bcast:31 into rows 2 and 3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+/* sum of exact integers kept as doubles (row sums of column numbers: below 2^53), over the wavefront, as lane 63's value */
+__device__ inline double waveSumExact(double v)
+{
+    auto moved = [](double x, auto ctrl, auto rowMask) {
+        constexpr int CTRL = decltype(ctrl)::value, MASK = decltype(rowMask)::value;
+        const int lo = dppMove<CTRL, MASK>(0, __double2loint(x)), hi = dppMove<CTRL, MASK>(0, __double2hiint(x));
+        return __hiloint2double(hi, lo); /* lanes outside the row mask receive +0.0 */
+    };
+    v += moved(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});
+    v += moved(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});
+    v += moved(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});
+    v += moved(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});
+    v += moved(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});
+    v += moved(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+/* set bits of a wave-wide mask below this lane */
+__device__ inline int bitsBelowLane(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+/* The value lane (l ^ M) holds, delivered to the lanes whose bit M is clear (what the phase sums' fold needs: only phase 0 uses the
+ * result), without the LDS queue: M = 8 a rotation inside the DPP row, M = 16 / 32 gfx950's row and half swaps
+ * (v_permlane16_swap / v_permlane32_swap).  In the other lanes the result is unspecified. */
+template <int M> __device__ inline unsigned partnerWord(unsigned w)
+{
+    static_assert(M == 8 || M == 16 || M == 32, "the folds of 8-, 4-, 2- and 1-row strips");
+    if constexpr (M == 8) {
+        return (unsigned)dppMove<0x128, 0xF>((int)w, (int)w); /* row_ror:8 */
+    } else if constexpr (M == 16) {
+        return __builtin_amdgcn_permlane16_swap(w, w, false, false)[1]; /* rows 0 and 2 receive rows 1 and 3 */
+    } else {
+        return __builtin_amdgcn_permlane32_swap(w, w, false, false)[1]; /* the lower half receives the upper half */
+    }
+}
+template <int M, typename T> __device__ inline T partnerOf(T v)
+{
+    constexpr int WORDS = (int)sizeof(T) / 4;
+    unsigned w[WORDS];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (int i = 0; i < WORDS; ++i)
+        w[i] = partnerWord<M>(w[i]);
+    T out;
+    __builtin_memcpy(&out, w, sizeof(T));
+    return out;
+}
+
 /* Most chunks a split sub-group may have (see SPLIT below): what the tightest tiled shape -- 48 KiB of LDS behind 2 048 rows --
  * can park when every one of its sub-groups is split.  fp64 / complex fp32: 3, fp32: 6, complex fp64: 1 (never split). */
 template <typename T> constexpr int kRaggedMostChunks = 49152 / (int)sizeof(T) / 2048;
@@ -76,7 +161,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
 #ifdef SPGPU_TRACE_BLOCKS
     /* experiment builds only: start / end time of every workgroup (100 MHz wall clock) into a caller-provided buffer */
     if (spgpuTraceBuffer && threadIdx.x == 0)
-        spgpuTraceBuffer[3 * (size_t)blockIdx.x] = wall_clock64();
+        spgpuTraceBuffer[8 * (size_t)blockIdx.x] = wall_clock64();
 #endif
     /* Consecutive workgroups (in row order) read overlapping slices of x.  The hardware deals workgroup ids round-robin
      * over the 8 XCDs, each with an L2 of its own: left alone, every slice is fetched from memory by all eight.  With
@@ -116,6 +201,20 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         if (threadIdx.x == 0)
             lowestDest = 0x7fffffff;
     }
+#ifdef SPGPU_TRACE_BLOCKS
+    /* (trace builds: 8 words per workgroup -- 0 start, 1 end, 2 tile in place, 3 lengths here, 4 probes here and tables written,
+     * 5 destinations staged, 6 first stages requested) */
+#define SPGPU_STAMP(word)                                                                                             \
+    do {                                                                                                              \
+        if (spgpuTraceBuffer && threadIdx.x == 0)                                                                     \
+            spgpuTraceBuffer[8 * (size_t)blockIdx.x + (word)] = wall_clock64();                                       \
+    } while (0)
+#else
+#define SPGPU_STAMP(word) do { } while (0)
+#endif
+    if (myLen[0] < 0)
+        return; /* (never: makes the stamp below wait for round trip 1) */
+    SPGPU_STAMP(3);
     ColumnProbe mine{0x7fffffff, -0x7fffffff - 1, 0, 0};
 #pragma unroll
     for (int j = 0; j < RPT; ++j) { /* round trip 2 */
@@ -126,17 +225,13 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
             last = a.rP[(long long)myBase[j] + (long long)(myLen[j] - 1) * a.idxStride];
         }
         /* depth of the 32-row sub-group these 32 lanes hold; the deep ones register and are cut at deepCap */
-        int depth = myLen[j];
-#pragma unroll
-        for (int m = 1; m < 32; m <<= 1) {
-            const int other = laneXor(depth, m);
-            depth = other > depth ? other : depth;
-        }
+        const int depth = halfReduce(myLen[j], MaxOf{});
         int slot = -1;
         if constexpr (DEEP) {
             if ((lane & 31) == 0 && depth > a.deepCap && i < ROWS)
                 slot = deepRegister(a, (int)(blockRow0 + i), depth, myBase[j]);
-            slot = __shfl(slot, lane & 32, kWave);
+            const int slotLow = __builtin_amdgcn_readlane(slot, 0), slotHigh = __builtin_amdgcn_readlane(slot, 32);
+            slot = (lane & 32) ? slotHigh : slotLow;
         }
         if (i < ROWS) {
             const int walked = (slot >= 0 && myLen[j] > a.deepKeep) ? a.deepKeep : myLen[j];
@@ -160,18 +255,14 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         }
     }
     if constexpr (XTILE) {
-        mine.lowest = waveMin(mine.lowest);
-        mine.highest = waveMax(mine.highest);
-#pragma unroll
-        for (int m = 1; m < kWave; m <<= 1) {
-            mine.rows += laneXor(mine.rows, m);
-            const int lowHalf = laneXor((int)(unsigned)(mine.middles & 0xffffffffll), m);
-            const int highHalf = laneXor((int)(mine.middles >> 32), m);
-            mine.middles += ((long long)highHalf << 32) | (unsigned)lowHalf;
-        }
+        mine.lowest = waveReduce(mine.lowest, MinOf{});
+        mine.highest = waveReduce(mine.highest, MaxOf{});
+        mine.rows = waveReduce(mine.rows, SumOf{});
+        mine.middles = (long long)waveSumExact((double)mine.middles); /* (a lane's sum of up to 4 column numbers: exact as a double) */
         if (lane == 0)
             seen[wave] = mine;
     }
+    SPGPU_STAMP(4);
     if (threadIdx.x == 0)
         nextItem = WAVES; /* the first WAVES sub-groups are dealt out statically */
     if constexpr (ZSTAGE) {
@@ -183,7 +274,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
             if (i < ROWS && blockRow0 + i < a.rows)
                 low = myDest[j] < low ? myDest[j] : low;
         }
-        low = waveMin(low);
+        low = waveReduce(low, MinOf{});
         if (lane == 0)
             atomicMin(&lowestDest, low);
     }
@@ -206,6 +297,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         /* (read by the wavefronts at the end of their first sub-group at the earliest: the tile's barrier lies between) */
     }
 
+    SPGPU_STAMP(5);
     /* ---- the per-sub-group state of a lane, and the stage loads --------------------------------------------------- */
     /* SPLIT (a.split > 0 columns): after the ordering every window has one sub-group some 250 columns deep at its head; walked
      * by one wavefront that is ~21 stages, 90 us, while the other seven finish the window's remaining 63 sub-groups in ~50.  A
@@ -216,15 +308,20 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     const int myDepthHere = lane < SUBS ? depths[lane] : 0;
     const bool mySplit = split > 0 && myDepthHere > split && myDepthHere <= a.deepCap;
     const int myChunks = lane < SUBS ? (mySplit ? (myDepthHere + split - 1) / split : 1) : 0;
-    int itemIncl = myChunks, parkIncl = mySplit ? myChunks : 0;
+    /* inclusive prefix sums over the lanes by counting bits: a sub-group has at most kRaggedMostChunks chunks, "lane l has at least
+     * K chunks" is one ballot per K, and the bits of it below a lane are one mbcnt (no cross-lane data movement at all) */
+    int itemIncl = myChunks, parkIncl = mySplit ? myChunks : 0, totalItems = 0, totalParks = 0;
+    {
+        constexpr int MOST = kRaggedMostChunks<T> > 1 ? kRaggedMostChunks<T> : 1;
 #pragma unroll
-    for (int m = 1; m < kWave; m <<= 1) {
-        const int items = __shfl_up(itemIncl, m, kWave), parks = __shfl_up(parkIncl, m, kWave);
-        itemIncl += lane >= m ? items : 0;
-        parkIncl += lane >= m ? parks : 0;
+        for (int K = 1; K <= MOST; ++K) {
+            const unsigned long long has = __ballot(myChunks >= K), parks = __ballot(mySplit && myChunks >= K);
+            itemIncl += bitsBelowLane(has);
+            parkIncl += bitsBelowLane(parks);
+            totalItems += __popcll(has);
+            totalParks += __popcll(parks);
+        }
     }
-    const int totalItems = __builtin_amdgcn_readfirstlane(__shfl(itemIncl, kWave - 1, kWave));
-    const int totalParks = __builtin_amdgcn_readfirstlane(__shfl(parkIncl, kWave - 1, kWave));
     const int tileRoom = TILE_ELEMS - totalParks * 32; /* >= 0: the host sized a.split for it (launchRagged) */
     T* const parked = tile + (tileRoom > 0 ? tileRoom : 0);
     if (lane < SUBS)
@@ -342,6 +439,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     for (int i = 0; i < AHEAD; ++i)
         fetchNext(ring[i]); /* on their way while the tile is being placed and filled */
 
+    SPGPU_STAMP(6);
     /* ---- the slice of x (round trip 3; the stages requested just above travel with it) ---------------------------- */
     int tileBase = 0;
     unsigned tileCount = 0;
@@ -388,7 +486,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
 
 #ifdef SPGPU_TRACE_BLOCKS
     if (spgpuTraceBuffer && threadIdx.x == 0)
-        spgpuTraceBuffer[3 * (size_t)blockIdx.x + 2] = wall_clock64(); /* tile in place */
+        spgpuTraceBuffer[8 * (size_t)blockIdx.x + 2] = wall_clock64(); /* tile in place */
 #endif
     /* ---- 4: the stage stream -------------------------------------------------------------------------------------- */
     const bool hasBeta = isNotZero(a.beta);
@@ -463,11 +561,14 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
                 sum[t] = pick(use[u][t], mulAdd(cur.st.v[u].v[t], xv[u][t], sum[t]), sum[t]);
         }
         if (last) { /* wavefront-uniform: the item is complete */
+            /* the PH phase sums of a row meet in phase 0: pairwise, own + partner, the order of the lane-xor tree */
 #pragma unroll
-            for (int m = LPC; m < kWave; m <<= 1) {
-#pragma unroll
-                for (int t = 0; t < RPL; ++t)
-                    sum[t] = add(sum[t], laneXor(sum[t], m));
+            for (int t = 0; t < RPL; ++t) {
+                if constexpr (LPC <= 8)
+                    sum[t] = add(sum[t], partnerOf<8>(sum[t]));
+                if constexpr (LPC <= 16)
+                    sum[t] = add(sum[t], partnerOf<16>(sum[t]));
+                sum[t] = add(sum[t], partnerOf<32>(sum[t]));
             }
             if (phase == 0) {
 #pragma unroll
@@ -522,7 +623,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     }
 #ifdef SPGPU_TRACE_BLOCKS
     if (spgpuTraceBuffer && lane == 0)
-        atomicMax(&spgpuTraceBuffer[3 * (size_t)blockIdx.x + 1], (unsigned long long)wall_clock64());
+        atomicMax(&spgpuTraceBuffer[8 * (size_t)blockIdx.x + 1], (unsigned long long)wall_clock64());
 #endif
 }
 

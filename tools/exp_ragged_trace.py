@@ -29,7 +29,7 @@ h = formats.coo_to_ordered_hell_device(handle, n, *coo, "D", 32, window, long_ro
 x = synth.device_vector(n, "D", 3)
 z = torch.zeros(n, dtype=torch.float64, device="cuda")
 groups = (n + rows_per_group - 1) // rows_per_group
-trace = torch.zeros(3 * groups + 16, dtype=torch.int64, device="cuda")
+trace = torch.zeros(8 * groups + 16, dtype=torch.int64, device="cuda")
 capi.lib.spgpuDebugSetTrace.argtypes = [C.c_void_p]
 call = lambda: capi.hellspmv["D"](handle, p(z), None, 1.0, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]), p(h["rIdx"]), 32, n,
                                   p(x), 0.0, 0)
@@ -42,7 +42,7 @@ capi.lib.spgpuDebugSetTrace(p(trace))
 call()
 torch.cuda.synchronize()
 capi.lib.spgpuDebugSetTrace(None)
-t = trace[:3 * groups].view(groups, 3).cpu().numpy().astype(np.float64)
+t = trace[:8 * groups].view(groups, 8).cpu().numpy().astype(np.float64)
 t0 = t[:, 0].min()
 start, end, tiled = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0
 span = end.max()
@@ -57,6 +57,14 @@ last_start = start.max()
 print(f"  last workgroup starts at {last_start:.1f} us ({span - last_start:.1f} us before the end); resident workgroups at that moment "
       f"{int(((start <= last_start) & (end > last_start)).sum())}; area idle after it: "
       f"{(slots * (span - last_start) - np.clip(end - np.maximum(start, last_start), 0, None).sum()) / (slots * span):.3f} of the launch")
+names = ["lengths here (round trip 1)", "probes here, tables written (round trip 2)", "destinations staged (two barriers)", "item table, first stages requested", "tile in place (round trip 3)"]
+marks = [t[:, 3], t[:, 4], t[:, 5], t[:, 6], t[:, 2]]
+previous = t[:, 0]
+for name, mark in zip(names, marks):
+    step = (mark - previous) / 100.0
+    ok = (mark > 0) & (step >= 0)
+    print(f"    prologue step -> {name}: median {np.median(step[ok]):.2f} us, p90 {np.percentile(step[ok], 90):.2f}")
+    previous = mark
 edges = np.linspace(0, span, 21)
 res = [int(((start <= (a + b) / 2) & (end > (a + b) / 2)).sum()) for a, b in zip(edges[:-1], edges[1:])]
 print("  resident workgroups at 20 moments:", res)
