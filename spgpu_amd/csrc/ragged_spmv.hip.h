@@ -24,64 +24,6 @@
  * Algorithmic bytes as for slabSpmvKernel, plus 4 per row for rIdx.
  */
 
-/* Cross-lane reductions of the prologue as DPP moves and readlanes (VALU / SALU only).  __shfl lowers to ds_bpermute, an LDS-queue
- * instruction: harmless in an idle CU, but the workgroup beside this one is streaming through its LDS tile at that moment and
- * every one of the ~70 dependent shuffles of the prologue waited its turn behind that traffic -- the prologue's compute-only
- * stretches measured 2-5 us each (profiles/r03_ragged_workgroup_trace.txt). */
-template <int CTRL, int ROW_MASK> __device__ inline int dppMove(int keep, int v)
-{
-    return __builtin_amdgcn_update_dpp(keep, v, CTRL, ROW_MASK, 0xF, false);
-}
-struct MaxOf { static constexpr int identity = -0x7fffffff - 1; __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
-struct MinOf { static constexpr int identity = 0x7fffffff; __device__ int operator()(int a, int b) const { return a < b ? a : b; } };
-struct SumOf { static constexpr int identity = 0; __device__ int operator()(int a, int b) const { return a + b; } };
-/* over the 16 lanes of each DPP row, result in every lane: neighbours, pairs, then the two mirrors */
-template <typename Op> __device__ inline int rowReduce(int v, Op op)
-{
-    v = op(v, dppMove<0xB1, 0xF>(v, v));  /* quad_perm [1,0,3,2] */
-    v = op(v, dppMove<0x4E, 0xF>(v, v));  /* quad_perm [2,3,0,1] */
-    v = op(v, dppMove<0x141, 0xF>(v, v)); /* row_half_mirror */
-    v = op(v, dppMove<0x140, 0xF>(v, v)); /* row_mirror */
-    return v;
-}
-/* over each 32-lane half of the wavefront, result in every lane of the half */
-template <typename Op> __device__ inline int halfReduce(int v, Op op)
-{
-    v = rowReduce(v, op);
-    v = op(v, dppMove<0x142, 0xA>(Op::identity, v)); /* row_bcast:15 into rows 1 and 3 */
-    const int low = __builtin_amdgcn_readlane(v, 31), high = __builtin_amdgcn_readlane(v, 63);
-    return (threadIdx.x & 32) ? high : low;
-}
-/* over the wavefront, as a scalar */
-template <typename Op> __device__ inline int waveReduce(int v, Op op)
-{
-    v = rowReduce(v, op);
-    v = op(v, dppMove<0x142, 0xA>(Op::identity, v)); /* row_bcast:15 into rows 1 and 3 */
-    v = op(v, dppMove<0x143, 0xC>(Op::identity, v)); /* row_bcast:31 into rows 2 and 3 */
-    return __builtin_amdgcn_readlane(v, 63);
-}
-/* sum of exact integers kept as doubles (row sums of column numbers: below 2^53), over the wavefront, as lane 63's value */
-__device__ inline double waveSumExact(double v)
-{
-    auto moved = [](double x, auto ctrl, auto rowMask) {
-        constexpr int CTRL = decltype(ctrl)::value, MASK = decltype(rowMask)::value;
-        const int lo = dppMove<CTRL, MASK>(0, __double2loint(x)), hi = dppMove<CTRL, MASK>(0, __double2hiint(x));
-        return __hiloint2double(hi, lo); /* lanes outside the row mask receive +0.0 */
-    };
-    v += moved(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});
-    v += moved(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});
-    v += moved(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});
-    v += moved(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});
-    v += moved(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});
-    v += moved(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
-}
-/* set bits of a wave-wide mask below this lane */
-__device__ inline int bitsBelowLane(unsigned long long mask)
-{
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
-
 /* The value lane (l ^ M) holds, delivered to the lanes whose bit M is clear (what the phase sums' fold needs: only phase 0 uses the
  * result), without the LDS queue: M = 8 a rotation inside the DPP row, M = 16 / 32 gfx950's row and half swaps
  * (v_permlane16_swap / v_permlane32_swap).  In the other lanes the result is unspecified. */
