@@ -325,6 +325,38 @@ def test_ragged_kernel_through_ridx_bit_exact(gpu, tuning, letter, shape, form, 
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
 
 
+@pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
+@pytest.mark.parametrize("pattern", ["near", "random"])
+def test_aligned_order_every_type_auto_bit_exact(gpu, letter, pattern):
+    """Rows ordered by spgpuOellOrderAlignedDevice (windows of 2 048, rows > 60 set aside), AUTO: the probe finds that the
+    kernel's 2 048-row blocks are the windows (answer 6) and the later calls run the 2 048-row shape (4- and 8-byte types;
+    complex fp64 keeps the default shape) -- every call, before and after the answer, equals the oracle bit for bit, with the
+    set-aside rows' columns beyond SPGPU_DEEP_KEEP in the deep kernels."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 9 * 2048 + 77
+    real = {"S": "S", "D": "D", "C": "S", "Z": "D"}[letter]
+    lengths = np.minimum(synth.power_law_lengths(n, 14.0, 900, 8), 900)
+    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 500, real, seed=5)
+    if letter in "CZ":
+        vals_t = torch.complex(vals_t, torch.flip(vals_t, [0]))
+    h = formats.coo_to_ordered_hell_device(gpu, n, rows_t, cols_t, vals_t, letter, 32, 2048, 60, aligned=True)
+    want_idx, _ = formats.oell_order(lengths, 2048, 60, aligned=True)
+    assert h["rIdx"].cpu().numpy().tobytes() == want_idx.tobytes()
+    sub = dict(letter=letter, rows=n, values=h["cM"][:h["slots"]].cpu().numpy(), indices=h["rP"][:h["slots"]].cpu().numpy(),
+               hack_offsets=h["hack_offsets"].cpu().numpy(), hack_size=32, row_lengths=h["rS"][:n].cpu().numpy(), base=0)
+    x, y = synth.values_for(letter, 21, n), synth.values_for(letter, 22, n)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    want = O.spmv_tail(sub, x, y, -0.5, 2.0, r_idx=want_idx, **O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP))
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    for call in range(4):
+        dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+        capi.hellspmv[letter](gpu, _dp(dz), _dp(dy), capi.scalar(letter, -0.5), _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]),
+                              _dp(h["rS"]), _dp(h["rIdx"]), 14, n, _dp(dx), capi.scalar(letter, 2.0), 0)
+        torch.cuda.synchronize()
+        assert dz.cpu().numpy().tobytes() == want.tobytes(), call
+
+
 @pytest.mark.parametrize("split", [0, 48, 96, 150])
 @pytest.mark.parametrize("letter,shape,form", [("D", 0, "auto"), ("D", 4, "auto"), ("S", 4, "auto"), ("C", 0, "gather"), ("Z", 4, "auto")])
 def test_split_sub_groups_bit_exact(gpu, tuning, letter, shape, form, split):
