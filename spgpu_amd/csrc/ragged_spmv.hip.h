@@ -88,7 +88,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     __shared__ unsigned short destOffset[ZSTAGE ? ROWS : 1];
     __shared__ __attribute__((aligned(16))) T staged[ZW];
     __shared__ unsigned stagedMask[ZW / 32];
-    __shared__ int lowestDest;
+    __shared__ int waveLowestDest[WAVES];
     __shared__ int2 subFacts[SUBS]; /* first item of the sub-group; first parked chunk sum, or -1 (one chunk) */
     __shared__ unsigned bases[ROWS / RPL]; /* first slot of every RPL-row strip, in elements (hackOffsets is an int array: a slot
                                               number plus the offset inside the hack fits 32 unsigned bits; 64-bit from here on) */
@@ -139,9 +139,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     }
     if constexpr (ZSTAGE) {
         if (threadIdx.x < ZW / 32)
-            stagedMask[threadIdx.x] = 0u;
-        if (threadIdx.x == 0)
-            lowestDest = 0x7fffffff;
+            stagedMask[threadIdx.x] = 0u; /* (long before the barrier below) */
     }
 #ifdef SPGPU_TRACE_BLOCKS
     /* (trace builds: 8 words per workgroup -- 0 start, 1 end, 2 tile in place, 3 lengths here, 4 probes here and tables written,
@@ -207,8 +205,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     SPGPU_STAMP(4);
     if (threadIdx.x == 0)
         nextItem = WAVES; /* the first WAVES sub-groups are dealt out statically */
-    if constexpr (ZSTAGE) {
-        __syncthreads(); /* lowestDest and stagedMask initialised */
+    if constexpr (ZSTAGE) { /* every wavefront's lowest destination: a word each, met behind the prologue's one barrier */
         int low = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
@@ -218,12 +215,13 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         }
         low = waveReduce(low, MinOf{});
         if (lane == 0)
-            atomicMin(&lowestDest, low);
+            waveLowestDest[wave] = low;
     }
     __syncthreads();
     int zBase = 0;
     if constexpr (ZSTAGE) {
-        zBase = lowestDest;
+        static_assert(WAVES <= 16, "one DPP row holds the wavefronts' words");
+        zBase = waveReduce(waveLowestDest[lane < WAVES ? lane : 0], MinOf{}); /* one LDS read per lane, the minimum by DPP */
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const int i = threadIdx.x + j * BLOCK;
