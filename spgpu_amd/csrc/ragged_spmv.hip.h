@@ -264,8 +264,11 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     }
     const int tileRoom = TILE_ELEMS - totalParks * 32; /* >= 0: the host sized a.split for it (launchRagged) */
     T* const parked = tile + (tileRoom > 0 ? tileRoom : 0);
-    if (lane < SUBS)
-        subFacts[lane] = int2{itemIncl - myChunks, mySplit ? parkIncl - myChunks : -1}; /* the same values from every wavefront */
+    if (lane < SUBS && wave == 0) /* (for the combine behind the stream, past a barrier) */
+        subFacts[lane] = int2{itemIncl - myChunks, mySplit ? parkIncl - myChunks : -1};
+    /* first parked chunk sum + 1 (0: one chunk) in the top 10 bits, the walked depth below: what loadItem asks lane s for */
+    static_assert(SUBS * kRaggedMostChunks<T> < 1023, "a park number fits 10 bits");
+    const int parkAndDepth = (int)(((unsigned)(mySplit ? parkIncl - myChunks + 1 : 0) << 22) | (unsigned)(myDepthHere < 0x3FFFFF ? myDepthHere : 0x3FFFFF));
     const unsigned long long splitOnes = __ballot(mySplit);
 
     struct Item {
@@ -288,10 +291,12 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         int strip = sub;
         asm volatile("" : "+v"(strip));
         const int s = __popcll(__ballot(lane < SUBS && itemIncl <= item));
-        const int2 facts = subFacts[s];
-        const int chunk = item - __builtin_amdgcn_readfirstlane(facts.x);
-        const int parkFirst = __builtin_amdgcn_readfirstlane(facts.y);
-        const int depth = depths[s];
+        /* lane s holds the sub-group's facts: read from its registers (v_readlane), not from LDS */
+        const int itemFirst = s > 0 ? __builtin_amdgcn_readlane(itemIncl, s - 1) : 0;
+        const int packedFacts = __builtin_amdgcn_readlane(parkAndDepth, s);
+        const int chunk = item - itemFirst;
+        const int parkFirst = (int)((unsigned)packedFacts >> 22) - 1;
+        const int depth = packedFacts & 0x3FFFFF;
         it.s = s;
         it.park = parkFirst >= 0 ? parkFirst + chunk : -1;
         it.kEnd = parkFirst >= 0 && (chunk + 1) * split < depth ? (chunk + 1) * split : depth;
@@ -384,15 +389,14 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     int tileBase = 0;
     unsigned tileCount = 0;
     if constexpr (XTILE) {
-        ColumnProbe all{0x7fffffff, -0x7fffffff - 1, 0, 0};
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const ColumnProbe other = seen[w];
-            all.lowest = other.lowest < all.lowest ? other.lowest : all.lowest;
-            all.highest = other.highest > all.highest ? other.highest : all.highest;
-            all.rows += other.rows;
-            all.middles += other.middles;
-        }
+        /* the wavefronts' probes meet: a lane reads ONE of them, the rest is DPP (every lane reading all WAVES of them was
+         * 24 LDS reads per lane behind the neighbour's traffic) */
+        const ColumnProbe one = lane < WAVES ? seen[lane] : ColumnProbe{0x7fffffff, -0x7fffffff - 1, 0, 0};
+        ColumnProbe all;
+        all.lowest = waveReduce(one.lowest, MinOf{});
+        all.highest = waveReduce(one.highest, MaxOf{});
+        all.rows = waveReduce(one.rows, SumOf{});
+        all.middles = (long long)waveSumExact((double)one.middles);
         if (all.rows > 0 && all.lowest >= 0) {
             const long long span = (long long)all.highest - all.lowest + 1;
             if (span <= tileRoom) {
