@@ -80,12 +80,12 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     __shared__ __attribute__((aligned(16))) T tile[TILE_ELEMS];
     /* row lengths as walked here (deep sub-groups: cut at deepCap); 16 bits each, 0xFFFF = "65 535 or more: ask rS" (a
      * row that long is walked whole only when the deep list was full) */
-    __shared__ unsigned short lens[ROWS];
+    __shared__ __attribute__((aligned(8))) unsigned short lens[ROWS];
     /* rIdx of the workgroup's rows (fetched from global memory at the end of a sub-group it would be waited for with vmcnt(0)
      * -- counters retire in order -- and drain the wavefront's prefetch); ZSTAGE: as offsets from the workgroup's lowest
      * destination instead, 0xFFFF = beyond the staging buffer */
     __shared__ int dests[ZSTAGE ? 1 : ROWS];
-    __shared__ unsigned short destOffset[ZSTAGE ? ROWS : 1];
+    __shared__ __attribute__((aligned(8))) unsigned short destOffset[ZSTAGE ? ROWS : 4];
     __shared__ __attribute__((aligned(16))) T staged[ZW];
     __shared__ unsigned stagedMask[ZW / 32];
     __shared__ int waveLowestDest[WAVES];
@@ -302,9 +302,11 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         it.kEnd = parkFirst >= 0 && (chunk + 1) * split < depth ? (chunk + 1) * split : depth;
         it.slab = (long long)bases[s * LPC + strip];
         it.longest = 0;
+        unsigned short stripLens[RPL]; /* the strip's RPL lengths in ONE LDS read */
+        __builtin_memcpy(stripLens, &lens[s * 32 + strip * RPL], sizeof(stripLens));
 #pragma unroll
         for (int t = 0; t < RPL; ++t) {
-            it.len[t] = lens[s * 32 + strip * RPL + t];
+            it.len[t] = stripLens[t];
             if (it.len[t] == 0xFFFF) { /* see lens: not cut (the sub-group has no deep slot), so the row's own length */
                 const long long r = blockRow0 + s * 32 + strip * RPL + t;
                 it.len[t] = a.rS ? a.rS[r] : a.maxNnz;
@@ -440,7 +442,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         sum[t] = zeroOf<T>();
 
     /* the sum of row `rowInSub` of sub-group s over the columns walked here is complete */
-    auto finishRow = [&](int s, int rowInSub, T rowSum) {
+    auto finishRow = [&](int s, int rowInSub, T rowSum, int knownOffset = -1) { /* knownOffset: the row's destOffset if the caller has read it */
         const long long r = blockRow0 + s * 32 + rowInSub;
         if (r >= a.rows)
             return;
@@ -448,7 +450,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         if (deepSlot >= 0) {
             a.deepPartials[(size_t)deepSlot * 32 + (size_t)rowInSub] = rowSum; /* the deep kernels finish the row */
         } else if constexpr (ZSTAGE) {
-            const unsigned off = destOffset[s * 32 + rowInSub];
+            const unsigned off = knownOffset >= 0 ? (unsigned)knownOffset : destOffset[s * 32 + rowInSub];
             if (off != 0xFFFFu) {
                 staged[off] = mul(a.alpha, rowSum); /* beta * y joins when the line is written */
             } else { /* beyond the staging buffer: the scattered store, its destination from global memory */
@@ -515,12 +517,16 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
                 sum[t] = add(sum[t], partnerOf<32>(sum[t]));
             }
             if (phase == 0) {
+                /* the strip's staged offsets in ONE LDS read (16 bits each, RPL of them side by side) */
+                unsigned short offs[RPL];
+                if constexpr (ZSTAGE)
+                    __builtin_memcpy(offs, &destOffset[s * 32 + sub * RPL], sizeof(offs));
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
                     if (park >= 0)
                         parked[park * 32 + sub * RPL + t] = sum[t]; /* a chunk of a split sub-group: combined below */
                     else
-                        finishRow(s, sub * RPL + t, sum[t]);
+                        finishRow(s, sub * RPL + t, sum[t], ZSTAGE ? (int)offs[t] : -1);
                 }
             }
 #pragma unroll
