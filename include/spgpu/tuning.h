@@ -51,6 +51,28 @@ extern "C" {
  * SPGPU_DEEP_CAP, or an order that sets the long rows aside.
  */
 int spgpuDeepListOverflows(spgpuHandle_t handle);
+/* The handle keeps a deep list for each of 8 streams.  A ninth stream takes over the list of the least recently used stream
+ * whose calls have all finished (spgpuDeepListsRecycled counts those hand-overs); while none is idle, an ordered SpMV on a stream
+ * without a list runs the stateless kernel (csrc/share_spmv.hip.h) -- correct, a different order of additions, slower --
+ * and spgpuDeepListFallbacks counts those calls. */
+int spgpuDeepListFallbacks(spgpuHandle_t handle);
+int spgpuDeepListsRecycled(spgpuHandle_t handle);
+
+/*
+ * Plans.  An ELL/HELL SpMV with a row order analyses a matrix the first time it sees it (behind the call, on its stream) and
+ * keeps what it learnt -- where the slice of x lies that each block of rows touches, which 32-row sub-groups are deeper
+ * than SPGPU_DEEP_CAP -- under the addresses of the matrix' arrays (8 matrices per handle).  Later calls on the same arrays run
+ * ONE launch with a shorter prologue: no probing of columns, no deep list, nothing behind the main kernel; the deep
+ * sub-groups get workgroups of their own in the same grid.  The bits of z are the same with and without a plan, and with a
+ * plan that has gone stale (another matrix at the same addresses): a plan decides who computes, never what or in which order.
+ * A stale plan is noticed by the kernels and rebuilt by the next call.  Launches captured into a HIP graph never use a plan.
+ *   SPGPU_PLAN=0                 no plans
+ *   SPGPU_PLAN_DEEP_PER_BLOCK    deep sub-groups per workgroup of theirs (default 4, 1 .. 8)
+ *   SPGPU_PLAN_DEEP_SPREAD       those workgroups are spread over the first N per cent of the grid (default 30; 0: all in front;
+ *                                -1: all behind the blocks of rows)
+ * spgpuSpmvPlanCounts: launches that ran with a plan, analyses started, plans found stale (any pointer may be NULL).
+ */
+void spgpuSpmvPlanCounts(spgpuHandle_t handle, int* uses, int* builds, int* stales);
 
 void spgpuTuningReload(void);
 /* 1 if the library was built with -DSPGPU_TUNING_VARIANTS: the non-default kernel shapes (SPGPU_SPMV_VARIANT, SPGPU_X_TILE_SHAPE,

@@ -256,6 +256,16 @@ FORM_AUTO, FORM_GATHER, FORM_STRIPS, FORM_XTILE, FORM_SWEEP = range(5)
 spgpuSetSpmvForm = _decl("spgpuSetSpmvForm", None, [Handle, i32])
 spgpuGetSpmvForm = _decl("spgpuGetSpmvForm", i32, [Handle])
 spgpuDeepListOverflows = _decl("spgpuDeepListOverflows", i32, [Handle])
+spgpuDeepListFallbacks = _decl("spgpuDeepListFallbacks", i32, [Handle])
+spgpuDeepListsRecycled = _decl("spgpuDeepListsRecycled", i32, [Handle])
+spgpuSpmvPlanCounts = _decl("spgpuSpmvPlanCounts", None, [Handle, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)])
+
+
+def plan_counts(handle):
+    """(launches with a plan, analyses started, plans found stale) of the handle's ordered ELL/HELL SpMVs (tuning.h)."""
+    u, b, s = i32(0), i32(0), i32(0)
+    spgpuSpmvPlanCounts(handle, C.byref(u), C.byref(b), C.byref(s))
+    return u.value, b.value, s.value
 spgpuGetLastSpmvForm = _decl("spgpuGetLastSpmvForm", i32, [Handle])
 spgpuTuningVariantsBuilt = _decl("spgpuTuningVariantsBuilt", i32, [])
 spgpuHellSpmvForm = _decl("spgpuHellSpmvForm", i32, [Handle, i32, ptr, i32, ptr, ptr, i32, i32])

@@ -30,14 +30,41 @@ static void deepListFor(SpgpuPrivateHandle* h, hipStream_t stream)
         known |= h->deepStream[i] == stream;
     if (!known && h->deepStreams < SPGPU_DEEP_STREAMS) {
         void* p = NULL;
+        hipEvent_t idle = NULL;
         if (hipMalloc(&p, DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES + DEEP_PARTIAL_BYTES + DEEP_ITEM_SUM_BYTES) == hipSuccess) {
-            if (hipMemset(p, 0, DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES) == hipSuccess) {
+            if (hipMemset(p, 0, DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES) == hipSuccess &&
+                hipEventCreateWithFlags(&idle, hipEventDisableTiming) == hipSuccess) {
                 h->deepScratch[h->deepStreams] = p;
                 h->deepStream[h->deepStreams] = stream;
+                h->deepIdle[h->deepStreams] = idle;
+                h->deepUsed[h->deepStreams] = 0;
+                h->deepClock[h->deepStreams] = ++h->deepTick;
                 h->deepStreams += 1;
             } else {
                 hipFree(p);
             }
+        }
+    } else if (!known) {
+        /* Every list has an owner.  A program that creates and destroys streams as it goes would fill the table with
+         * the lists of streams that no longer exist, and every ordered SpMV on a later stream would run the kernel that
+         * needs no list for good (slower, another order of additions).  So the list that was used longest ago AND whose
+         * last user has finished -- the event recorded behind its deep kernels has completed, or it was never used --
+         * changes hands: its header is zero (the last finishing workgroup of a call leaves it so), nothing else of it
+         * carries over from call to call. */
+        int pick = -1;
+        for (int i = 0; i < h->deepStreams; ++i) {
+            if (h->deepStream[i] == h->pub.defaultStream)
+                continue; /* the default stream always comes back (spgpuSetStream(h, 0)) */
+            if (h->deepUsed[i] && hipEventQuery(h->deepIdle[i]) != hipSuccess)
+                continue;
+            if (pick < 0 || h->deepClock[i] < h->deepClock[pick])
+                pick = i;
+        }
+        if (pick >= 0) {
+            h->deepStream[pick] = stream;
+            h->deepUsed[pick] = 0;
+            h->deepClock[pick] = ++h->deepTick;
+            h->deepRecycled += 1;
         }
     }
     pthread_mutex_unlock(&h->formLock);
@@ -100,6 +127,20 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     h->spmvForm = SPGPU_SPMV_FORM_AUTO;
     hipSetDevice(device);
     deepListFor(h, h->pub.defaultStream); /* failing that, ordered matrices run the kernel that needs no list */
+    /* the plan table (spgpu_internal.h): failing this, ordered matrices run without plans */
+    h->plans = (SpgpuSpmvPlan*)calloc(SPGPU_PLANS, sizeof(SpgpuSpmvPlan));
+    if (h->plans && hipHostMalloc((void**)&h->planPinned, SPGPU_PLANS * SPGPU_PLAN_WORDS * sizeof(int), hipHostMallocDefault) == hipSuccess) {
+        memset(h->planPinned, 0, SPGPU_PLANS * SPGPU_PLAN_WORDS * sizeof(int));
+        for (int i = 0; i < SPGPU_PLANS; ++i) {
+            h->plans[i].pinned = h->planPinned + i * SPGPU_PLAN_WORDS;
+            if (hipEventCreateWithFlags(&h->plans[i].built, hipEventDisableTiming) != hipSuccess)
+                h->plans[i].state = SPGPU_PLAN_GIVEN_UP;
+        }
+    } else {
+        free(h->plans);
+        h->plans = NULL;
+        h->planPinned = NULL;
+    }
     hipSetDevice(previous);
 
     *pHandle = &h->pub;
@@ -119,8 +160,23 @@ void spgpuDestroy(spgpuHandle_t pHandle)
      * for defaultStream, before freeing them.  A graph captured from this handle must not be replayed after this. */
     hipDeviceSynchronize();
     hipFree(h->reduceScratch);
-    for (int i = 0; i < h->deepStreams; ++i)
+    for (int i = 0; i < h->deepStreams; ++i) {
         hipFree(h->deepScratch[i]);
+        hipEventDestroy(h->deepIdle[i]);
+    }
+    if (h->plans) {
+        for (int i = 0; i < SPGPU_PLANS; ++i) {
+            if (h->plans[i].device)
+                hipFree(h->plans[i].device);
+            if (h->plans[i].built)
+                hipEventDestroy(h->plans[i].built);
+        }
+        free(h->plans);
+    }
+    for (int i = 0; i < h->planGraves; ++i)
+        hipFree(h->planGraveyard[i]);
+    if (h->planPinned)
+        hipHostFree(h->planPinned);
     hipHostFree(h->reduceHost);
     hipHostFree(h->formFeedback);
     hipStreamDestroy(h->pub.defaultStream);
@@ -154,9 +210,8 @@ void spgpuSetStream(spgpuHandle_t pHandle, hipStream_t stream)
     pthread_mutex_lock(&h->formLock);
     for (int i = 0; i < h->deepStreams; ++i)
         known |= h->deepStream[i] == h->pub.currentStream;
-    const int room = h->deepStreams < SPGPU_DEEP_STREAMS;
     pthread_mutex_unlock(&h->formLock);
-    if (!known && room) {
+    if (!known) {
         int previous = 0;
         hipGetDevice(&previous);
         hipSetDevice(h->pub.device);
@@ -215,8 +270,14 @@ spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, SpgpuDeepList* list)
     char* base = NULL;
     pthread_mutex_lock(&h->formLock);
     for (int i = 0; i < h->deepStreams; ++i)
-        if (h->deepStream[i] == h->pub.currentStream)
+        if (h->deepStream[i] == h->pub.currentStream) {
             base = (char*)h->deepScratch[i];
+            list->idle = h->deepIdle[i];
+            h->deepUsed[i] = 1;
+            h->deepClock[i] = ++h->deepTick;
+        }
+    if (!base)
+        h->deepFallbacks += 1;
     pthread_mutex_unlock(&h->formLock);
     if (!base)
         return SPGPU_UNSUPPORTED;
@@ -243,6 +304,111 @@ int* spgpuDeepOverflowWords(spgpuHandle_t pHandle)
 int spgpuDeepListOverflows(spgpuHandle_t pHandle)
 {
     return ((volatile int*)spgpuDeepOverflowWords(pHandle))[0];
+}
+
+int spgpuDeepListFallbacks(spgpuHandle_t pHandle)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    pthread_mutex_lock(&h->formLock);
+    const int n = h->deepFallbacks;
+    pthread_mutex_unlock(&h->formLock);
+    return n;
+}
+
+int spgpuDeepListsRecycled(spgpuHandle_t pHandle)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    pthread_mutex_lock(&h->formLock);
+    const int n = h->deepRecycled;
+    pthread_mutex_unlock(&h->formLock);
+    return n;
+}
+
+/* ---- per-matrix plans of the ordered ELL/HELL SpMV (spgpu_internal.h, csrc/planned_spmv.hip) ---- */
+void spgpuPlanLock(spgpuHandle_t pHandle)
+{
+    pthread_mutex_lock(&spgpuPrivate(pHandle)->formLock);
+}
+
+void spgpuPlanUnlock(spgpuHandle_t pHandle)
+{
+    pthread_mutex_unlock(&spgpuPrivate(pHandle)->formLock);
+}
+
+void spgpuPlanRetire(spgpuHandle_t pHandle, SpgpuSpmvPlan* plan)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    if (plan->device) {
+        if (h->planGraves == SPGPU_PLAN_GRAVES) {
+            /* kernels in flight on any stream may still read a retired plan: wait for the device before the buffers go
+             * (once per SPGPU_PLAN_GRAVES retirements; never while a stream of the process captures -- see launchPlanned) */
+            hipDeviceSynchronize();
+            for (int i = 0; i < h->planGraves; ++i)
+                hipFree(h->planGraveyard[i]);
+            h->planGraves = 0;
+        }
+        h->planGraveyard[h->planGraves++] = plan->device;
+        plan->device = NULL;
+    }
+    plan->state = SPGPU_PLAN_EMPTY;
+    plan->uses = 0;
+    plan->deep = 0;
+    plan->pinned[0] = 0;
+    plan->pinned[1] = 0;
+}
+
+static int samePlanKey(const SpgpuSpmvPlan* a, const SpgpuSpmvPlan* b)
+{
+    return a->rP == b->rP && a->rS == b->rS && a->rIdx == b->rIdx && a->hackOffsets == b->hackOffsets &&
+           a->idxStride == b->idxStride && a->rows == b->rows && a->hackSize == b->hackSize && a->baseIndex == b->baseIndex &&
+           a->maxNnz == b->maxNnz && a->deepCap == b->deepCap && a->subs == b->subs;
+}
+
+SpgpuSpmvPlan* spgpuPlanRecord(spgpuHandle_t pHandle, const SpgpuSpmvPlan* key)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    if (!h->plans)
+        return NULL;
+    SpgpuSpmvPlan* oldest = NULL;
+    for (int i = 0; i < SPGPU_PLANS; ++i) {
+        SpgpuSpmvPlan* p = &h->plans[i];
+        if (p->rows > 0 && samePlanKey(p, key)) {
+            p->clock = ++h->planClock;
+            return p;
+        }
+        /* a record whose analysis is still in flight keeps its buffer and its pinned words until it has landed */
+        if (p->state == SPGPU_PLAN_BUILDING && hipEventQuery(p->built) != hipSuccess)
+            continue;
+        if (!oldest || p->rows == 0 || (oldest->rows != 0 && p->clock < oldest->clock))
+            oldest = p;
+    }
+    if (!oldest)
+        return NULL;
+    const int givenUp = oldest->built == NULL; /* (its event could not be created: spgpuCreate) */
+    spgpuPlanRetire(pHandle, oldest);
+    int* pinned = oldest->pinned;
+    hipEvent_t built = oldest->built;
+    *oldest = *key;
+    oldest->pinned = pinned;
+    oldest->built = built;
+    oldest->device = NULL;
+    oldest->state = givenUp ? SPGPU_PLAN_GIVEN_UP : SPGPU_PLAN_EMPTY;
+    oldest->stales = 0;
+    oldest->uses = 0;
+    oldest->deep = 0;
+    oldest->blocks = 0;
+    oldest->clock = ++h->planClock;
+    return oldest;
+}
+
+void spgpuSpmvPlanCounts(spgpuHandle_t pHandle, int* uses, int* builds, int* stales)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    pthread_mutex_lock(&h->formLock);
+    if (uses) *uses = h->planUses;
+    if (builds) *builds = h->planBuilds;
+    if (stales) *stales = h->planStales;
+    pthread_mutex_unlock(&h->formLock);
 }
 
 /* ---- per-handle kernel-form hint (include/spgpu/tuning.h) ---- */
@@ -301,6 +467,9 @@ void spgpuTuningReload(void)
     t.pipeGroups = envInt("SPGPU_PIPE_GROUPS", 0);
     t.raggedSplit = envInt("SPGPU_RAGGED_SPLIT", -1);
     t.l1Nt = envInt("SPGPU_L1_NT", -1);
+    t.plan = envInt("SPGPU_PLAN", 1);
+    t.planDeepSpread = envInt("SPGPU_PLAN_DEEP_SPREAD", 30);
+    t.planDeepPerBlock = envInt("SPGPU_PLAN_DEEP_PER_BLOCK", 4);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);
 }

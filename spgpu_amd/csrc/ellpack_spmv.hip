@@ -44,6 +44,7 @@
 #include "numeric.hip.h"
 #include <type_traits>
 #include "spgpu_internal.h"
+#include "slab_args.hip.h"
 
 #include "spgpu/ell.h"
 #include "spgpu/hell.h"
@@ -53,101 +54,12 @@
 
 namespace spgpu {
 
-template <typename T> struct SlabArgs {
-    T* z;
-    const T* y;
-    const T* x;
-    const T* cM;
-    const int* rP;
-    const int* rS;          /* NULL: every row has maxNnz slots (ELL only) */
-    const int* rIdx;        /* NULL: identity */
-    const int* hackOffsets; /* HELL only */
-    T alpha, beta;
-    int rows;
-    int baseIndex;
-    int hackSize; /* HELL only */
-    int maxNnz;   /* ELL without rS */
-    long long valStride, idxStride; /* elements between two slab columns */
-    int wideIO;   /* y and z are aligned for RPL-wide access */
-    int tailLanes; /* TAIL kernels: switch to whole-wave rows when <= this many lanes are busy */
-    int* feedback; /* pinned host ints the sample wavefronts report the form they saw to, or NULL */
-    long long tileSpanLimit; /* a sample group whose columns span at most this many counts as "local" (x-tile form) */
-    /* DEEP kernels: 32-row sub-groups deeper than deepCap hand their columns >= deepCap to the deep kernels */
-    int deepCap;
-    int deepKeep;                /* of a sub-group deeper than deepCap the main kernel walks the first deepKeep columns (<= deepCap); the rest are items */
-    int deepChunk;               /* columns per item */
-    int* deepHeader;             /* entries registered, items handed out (may exceed the capacities), finish ticket */
-    SpgpuDeepEntry* deepEntries; /* [SPGPU_DEEP_ENTRIES] */
-    SpgpuDeepItem* deepItems;    /* [SPGPU_DEEP_ITEMS] */
-    T* deepPartials;             /* [SPGPU_DEEP_ENTRIES][32] row sums over the columns < deepCap */
-    T* deepItemSums;             /* [SPGPU_DEEP_ITEMS][32] */
-    int* deepOverflow;           /* pinned: calls that overflowed the list, and what the last of them asked for */
-    int xcdRun;                  /* raggedSpmvKernel: row blocks per XCD run (0: hardware order) */
-    int pipeRanges;              /* pipeSpmvKernel: ranges per workgroup */
-    int avgNnzPerRow;            /* the caller's hint (0: none) */
-    int split;                   /* raggedSpmvKernel: columns per chunk of a split sub-group (0: none) */
-};
-
-constexpr int kBlockThreads = 256;
-constexpr int kTailLanes = 16; /* switch to whole-wave row processing when <= this many lanes are busy
-                                  (measured flat between 4 and 16 for the 1-phase kernel, worse above) */
-constexpr int kTailUnroll = 4; /* entries per lane in flight in tail mode */
-
-/* Cache policy of the x gathers (experiments, -DSPGPU_TUNING_VARIANTS): 0 default, 1 non-temporal,
- * 2 agent-scope (sc1: bypasses the per-CU L1). */
-template <int POLICY, typename T> __device__ inline T loadX(const T* p)
-{
-    if constexpr (POLICY == 1) {
-        using Raw = typename RawBits<sizeof(T)>::type;
-        Raw raw = __builtin_nontemporal_load(reinterpret_cast<const Raw*>(p));
-        T out;
-        __builtin_memcpy(&out, &raw, sizeof(T));
-        return out;
-    } else if constexpr (POLICY == 2 && sizeof(T) == 8) {
-        unsigned long long raw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-        T out;
-        __builtin_memcpy(&out, &raw, sizeof(T));
-        return out;
-    } else {
-        return *p;
-    }
-}
-
-/* One lane registers a 32-row sub-group deeper than deepCap in the handle's deep list: an entry, and one item per
- * deepChunk columns beyond the cap.  Returns the entry, or -1 when the list is full -- the sub-group then stays with
- * the main kernel.  (The list is global: which entry a sub-group gets depends on scheduling, its sum does not.) */
-template <typename T> __device__ inline int deepRegister(const SlabArgs<T>& a, int row0, int depth, unsigned base)
-{
-    const int items = (depth - a.deepKeep + a.deepChunk - 1) / a.deepChunk;
-    const int entry = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES], 1);
-    if (entry >= SPGPU_DEEP_ENTRIES)
-        return -1;
-    const int first = atomicAdd(&a.deepHeader[SPGPU_DEEP_HEAD_ITEMS], items);
-    const bool fits = first + items <= SPGPU_DEEP_ITEMS;
-    a.deepEntries[entry] = SpgpuDeepEntry{row0, depth, first, fits ? items : 0};
-    if (!fits) {
-        if (first < SPGPU_DEEP_ITEMS) /* the slots from `first` on keep what an earlier call left: nobody may read them */
-            atomicMax(&a.deepHeader[SPGPU_DEEP_HEAD_CUT], SPGPU_DEEP_ITEMS - first);
-        return -1;
-    }
-    for (int c = 0; c < items; ++c)
-        a.deepItems[first + c] = SpgpuDeepItem{row0, base, depth, c};
-    return entry;
-}
-
 /* Function-scope LDS: only kernels that call this allocate it (the forms without a tile keep 0 bytes of LDS). */
 template <typename E, int N> __device__ inline E* ldsArray()
 {
     __shared__ __attribute__((aligned(16))) E buffer[N];
     return buffer;
 }
-
-/* What one wavefront saw of its rows' columns (XTILE probe). */
-struct ColumnProbe {
-    int lowest, highest, rows;
-    long long middles; /* sum over sampled rows of (first + last column) / 2 */
-};
 
 /* The wavefronts that report the form they ran in: about the quarter points of the matrix, nudged off them -- grid
  * problems put their boundary rows (the ones that never qualify) exactly on power-of-two row numbers. */
@@ -1078,8 +990,10 @@ __global__ __launch_bounds__(kBlockThreads) void sweepSpmvKernel(const SlabArgs<
 __device__ unsigned long long* spgpuTraceBuffer;
 #endif
 #include "ragged_spmv.hip.h"
+#ifdef SPGPU_TUNING_VARIANTS
 #include "share_spmv.hip.h"
 #include "pipe_spmv.hip.h"
+#endif
 
 /* ---- host side ----------------------------------------------------------- */
 
@@ -1174,7 +1088,6 @@ static void launchSweep(hipStream_t stream, const SlabArgs<T>& a)
 
 /* Right behind a DEEP kernel.  Fixed grids (the number of items is known on the device only): with nothing
  * registered both kernels read the header and leave. */
-constexpr int kDeepChunk = 64; /* measured: items of 32 / 64 / 128 columns and stages of 16 / 32 within 8 % -- the kernel is bound by the lines its gathers pull */
 template <typename T, int RPL, bool IS_HELL>
 static void launchDeep(hipStream_t stream, const SlabArgs<T>& a)
 {
@@ -1293,8 +1206,9 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     a.deepItemSums = nullptr;
     a.deepOverflow = spgpuDeepOverflowWords(handle);
     bool noDeepList = false;
+    SpgpuDeepList list;
+    list.idle = nullptr;
     if (deepSplit) {
-        SpgpuDeepList list;
         if (spgpuDeepScratch(handle, &list) == SPGPU_SUCCESS) {
             a.deepHeader = list.header;
             a.deepEntries = list.entries;
@@ -1306,6 +1220,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             noDeepList = true;
         }
     }
+#ifdef SPGPU_TUNING_VARIANTS /* two stateless one-launch kernels of round 3, kept for A/B runs (another order of additions: chunks of 48 columns) */
     if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && tune->ragged == 3) {
         /* rows ordered by length: one resident workgroup per CU, the next block prepared beside the stream (pipe_spmv.hip.h) */
         a.wideIO = 0;
@@ -1314,15 +1229,15 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         launchPipe<T, WIDE, IS_HELL>(stream, a, tune->pipeGroups > 0 ? tune->pipeGroups : handle->multiProcessorCount, form != SPGPU_SPMV_FORM_GATHER, tune->raggedShape);
         return;
     }
-    if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && (tune->ragged == 2 || (noDeepList && tune->ragged != 0))) {
-        /* rows ordered by length: shares of equal work, one launch, no state (share_spmv.hip.h) -- asked for, or this
-         * stream of the handle has no deep list (more than SPGPU_DEEP_STREAMS streams, or its allocation failed) */
+    if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && tune->ragged == 2) {
+        /* rows ordered by length: shares of equal work, one launch, no state (share_spmv.hip.h) */
         a.wideIO = 0;
         a.feedback = nullptr;
         spgpuNoteSpmvForm(handle, form != SPGPU_SPMV_FORM_GATHER ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
         launchShare<T, WIDE, IS_HELL>(stream, a, tune->raggedShape, form != SPGPU_SPMV_FORM_GATHER);
         return;
     }
+#endif
     /* ELL says how long its longest row is: when none can exceed the cap nothing registers and the two launches behind
      * the main kernel (~5 us each when empty) are left out; HELL does not say */
     const bool deepPossible = IS_HELL || a.maxNnz > a.deepCap;
@@ -1331,7 +1246,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
 #else
     constexpr bool queueKernelOnly = false;
 #endif
-    if (deepSplit && (tune->ragged != 0 || queueKernelOnly)) {
+    if ((deepSplit || noDeepList) && (tune->ragged != 0 || queueKernelOnly)) {
         /* the queue-driven kernel for rows ordered by length (ragged_spmv.hip.h); x through an LDS tile unless the
          * caller asked for plain gathers */
         a.wideIO = 0;
@@ -1349,9 +1264,21 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
                                    a.idxStride, a.maxNnz, a.rows, a.baseIndex, seen + 3);
             shape = said == 4 || said == 6 ? 4 : 0; /* 6: the blocks are the windows of an aligned order */
         }
+        /* a matrix seen before has a plan (planned_spmv.hip): one launch, the deep sub-groups in workgroups of their own, no
+         * list.  Same bits either way. */
+        /* noDeepList: this stream of the handle has no deep list (every list belongs to a stream with work in flight, or the
+         * allocation failed): the same kernel family without any state -- the matrix' plan if it is ready, else no plan at
+         * all (every deep sub-group worked off by its own block).  Same bits in every case. */
+        const bool tiledForm = form != SPGPU_SPMV_FORM_GATHER;
+        if (noDeepList && !(shape == 4 || shape == 5))
+            shape = 0;
+        if ((!tiledForm || shape == 0 || shape == 4 || shape == 5) && launchPlanned<T, IS_HELL>(handle, stream, a, shape, tiledForm, noDeepList))
+            return;
         const bool deepKernels = launchRagged<T, WIDE, IS_HELL, true>(stream, a, shape, form != SPGPU_SPMV_FORM_GATHER);
         if (deepPossible && deepKernels)
             launchDeep<T, WIDE, IS_HELL>(stream, a);
+        if (list.idle)
+            (void)hipEventRecord(list.idle, stream); /* complete = the list has no user (core.c: a list may change hands) */
         return;
     }
 #ifdef SPGPU_TUNING_VARIANTS
@@ -1433,12 +1360,14 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             default: /* 21 */
                 if (tiled || autoTile)
                     launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
-                else if (a.avgNnzPerRow > 0 && a.avgNnzPerRow <= 8 && form == SPGPU_SPMV_FORM_AUTO) {
+                else if (a.avgNnzPerRow > 0 && a.avgNnzPerRow <= 8 && form == SPGPU_SPMV_FORM_AUTO && (IS_HELL || a.maxNnz <= 16)) {
                     /* the caller says the rows are short (avgNnzPerRow: the reference's own tuning hint, which picks its
                      * threads-per-row shape, hell_spmv_base_template.cuh:306-325): such a row is one stage, and a kernel
                      * without the prefetch ring needs a third of the registers -- all wavefronts of a 1 M-row system are
                      * resident at once instead of queueing in three rounds (19.4 -> 17.4 us on configs[0]).  Same order of
-                     * additions (the tail switch is considered every 8 columns, as in the default kernel). */
+                     * additions (the tail switch is considered every 8 columns, as in the default kernel:
+                     * tests/test_gpu_spmv.py::test_short_row_hint_same_bits pins that on rows of 0 .. 300 entries).  ELL says how long
+                     * its longest row is: beyond two stages the prefetching kernel stays, whatever the average; HELL has only the hint. */
                     spgpuNoteSpmvForm(handle, SPGPU_SPMV_FORM_GATHER);
                     a.feedback = nullptr;
                     launchLean<T, WIDE, IS_HELL>(stream, a);
@@ -1644,9 +1573,11 @@ int spgpuEllSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int 
 }
 
 #ifdef SPGPU_TRACE_BLOCKS
+void spgpuPlannedSetTrace(unsigned long long* buffer);
 void spgpuDebugSetTrace(unsigned long long* buffer)
 {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(spgpu::spgpuTraceBuffer), &buffer, sizeof(buffer));
+    spgpuPlannedSetTrace(buffer);
 }
 #endif
 

@@ -55,7 +55,16 @@ template <int M, typename T> __device__ inline T partnerOf(T v)
  * can park when every one of its sub-groups is split.  fp64 / complex fp32: 3, fp32: 6, complex fp64: 1 (never split). */
 template <typename T> constexpr int kRaggedMostChunks = 49152 / (int)sizeof(T) / 2048;
 
-template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int TILE_BYTES, int SUBS, bool DEEP, int ZBYTES = 0>
+#include "deep_rows.hip.h"
+
+/* PLAN (planned_spmv.hip): the matrix has a plan (spgpu_internal.h).  Two of the prologue's three dependent round trips
+ * are then one -- the block's record says where its slice of x lies, so nobody asks every row for its first and last column
+ * -- and nothing registers anywhere: the sub-groups the plan lists as deep are skipped here and worked off by workgroups of
+ * their own at the end (or the start) of the same grid (deep_rows.hip.h).  What the plan says is never trusted for WHAT is
+ * computed: lengths, bases, destinations and the depth that decides a sub-group's chunks are read from the matrix; a
+ * sub-group deeper than deepCap that the plan does not list (a stale plan) is worked off behind the block's own stream, by
+ * the same routine, in the same order of additions. */
+template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int TILE_BYTES, int SUBS, bool DEEP, int ZBYTES = 0, bool PLAN = false>
 __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4)))
 void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavefront workgroups per CU (what LDS admits) */
 {
@@ -66,7 +75,11 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     constexpr int ROWS = SUBS * 32;
     constexpr bool XTILE = TILE_BYTES > 0;
     /* (the gather form has no tile, only room for the chunk sums of its split sub-groups: the sums must not depend on the form) */
-    constexpr int TILE_ELEMS = XTILE ? TILE_BYTES / (int)sizeof(T) : (kRaggedMostChunks<T> >= 2 ? SUBS * 32 * kRaggedMostChunks<T> : 1);
+    /* BEHIND: deep sub-groups nobody else takes are worked off by this workgroup behind its stream; that routine borrows the tile */
+    constexpr bool BEHIND = DEEP;
+    constexpr int CHUNK_ROOM = kRaggedMostChunks<T> >= 2 ? SUBS * 32 * kRaggedMostChunks<T> : 1;
+    constexpr int BEHIND_ROOM = BEHIND ? 16384 / (int)sizeof(T) : 1;
+    constexpr int TILE_ELEMS = XTILE ? TILE_BYTES / (int)sizeof(T) : (CHUNK_ROOM > BEHIND_ROOM ? CHUNK_ROOM : BEHIND_ROOM);
     static_assert(TILE_ELEMS >= SUBS * 32 * kRaggedMostChunks<T> || kRaggedMostChunks<T> < 2, "room for every chunk sum");
     /* ZSTAGE: the workgroup's results wait in LDS, placed by destination, and leave in whole lines when its queue is empty.
      * The L2 does not merge stores over time (every store's bytes leave it at once): written from the lanes that hold the
@@ -76,6 +89,8 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     constexpr int ZW = ZSTAGE ? ZBYTES / (int)sizeof(T) : 32;
     static_assert(ZW < 0xFFFF && ZW % 32 == 0, "a staged destination is a 16-bit offset");
     static_assert(SUBS >= WAVES, "every wavefront starts with a sub-group of its own");
+    static_assert(!PLAN || (DEEP && SUBS <= 64), "a plan record holds a 64-bit mask");
+    static_assert(!BEHIND || TILE_ELEMS * (int)sizeof(T) >= 16384, "the deep routine borrows the tile");
 
     __shared__ __attribute__((aligned(16))) T tile[TILE_ELEMS];
     /* row lengths as walked here (deep sub-groups: cut at deepCap); 16 bits each, 0xFFFF = "65 535 or more: ask rS" (a
@@ -108,7 +123,39 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     /* Consecutive workgroups (in row order) read overlapping slices of x.  The hardware deals workgroup ids round-robin
      * over the 8 XCDs, each with an L2 of its own: left alone, every slice is fetched from memory by all eight.  With
      * a.xcdRun > 0 the id is permuted so that runs of xcdRun consecutive row blocks share an XCD (speed only). */
-    const unsigned logicalBlock = a.xcdRun > 0 ? xcdRuns(blockIdx.x, gridDim.x, (unsigned)a.xcdRun) : blockIdx.x;
+    unsigned mainId = blockIdx.x, mainBlocks = gridDim.x;
+    if constexpr (PLAN) {
+        /* the grid: planMainBlocks workgroups that own blocks of rows, and one for every planDeepPerBlock deep sub-groups.  The
+         * latter live long on little bandwidth (their x comes from global memory, a round trip per stage): they are spread
+         * over the front part of the grid, one at every planDeepStride-th place, so that they run beside many blocks of rows and
+         * are done long before the launch ends (planDeepStride 0: all of them behind the blocks of rows).  Sub-groups are dealt to
+         * them round-robin -- neighbours in the list are about equally deep, so every such workgroup gets a bit of everything. */
+        mainBlocks = (unsigned)a.planMainBlocks;
+        const unsigned deepBlocks = gridDim.x - mainBlocks, stride = (unsigned)a.planDeepStride;
+        bool deepBlock;
+        unsigned deepId;
+        if (stride == 0u) {
+            deepBlock = blockIdx.x >= mainBlocks;
+            deepId = blockIdx.x - mainBlocks;
+        } else {
+            deepId = blockIdx.x / stride;
+            deepBlock = blockIdx.x % stride == 0u && deepId < deepBlocks;
+            const unsigned before = (blockIdx.x + stride - 1u) / stride;
+            mainId = blockIdx.x - (before < deepBlocks ? before : deepBlocks);
+        }
+        if (deepBlock) {
+            int count = 0;
+            for (int j = 0; j < a.planDeepPerBlock; ++j)
+                count += (long long)deepId + (long long)j * deepBlocks < a.planDeep ? 1 : 0;
+            wholeSubgroups<T, RPL, IS_HELL, WAVES, TILE_ELEMS * (int)sizeof(T)>(a, tile, count, [&](int j) { return a.planDeepSubs[deepId + (unsigned)j * deepBlocks]; }, true);
+#ifdef SPGPU_TRACE_BLOCKS
+            if (spgpuTraceBuffer && lane == 0)
+                atomicMax(&spgpuTraceBuffer[8 * (size_t)blockIdx.x + 1], (unsigned long long)wall_clock64());
+#endif
+            return;
+        }
+    }
+    const unsigned logicalBlock = a.xcdRun > 0 ? xcdRuns(mainId, mainBlocks, (unsigned)a.xcdRun) : mainId;
     const long long blockRow0 = (long long)logicalBlock * ROWS;
     const T* __restrict__ x = a.x;
 
@@ -120,6 +167,13 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     constexpr int RPT = (ROWS + BLOCK - 1) / BLOCK; /* rows a thread looks at; 32 consecutive rows = 32 consecutive lanes */
     int myLen[RPT], myDest[RPT];
     unsigned myBase[RPT];
+    bool stagedHere[RPT]; /* the row's result is this stream's to finish */
+    constexpr int kHere = 0, kElsewhere = 1, kBehind = 2;
+    SpgpuPlanBlock planned{};
+    if constexpr (PLAN) {
+        if (a.planBlocks) /* (workgroup-uniform: scalar loads, no exchange; no plan: nothing listed, no tile -- the stateless fallback) */
+            planned = a.planBlocks[logicalBlock];
+    }
 #pragma unroll
     for (int j = 0; j < RPT; ++j) { /* round trip 1 */
         const int i = threadIdx.x + j * BLOCK;
@@ -160,32 +214,44 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     for (int j = 0; j < RPT; ++j) { /* round trip 2 */
         const int i = threadIdx.x + j * BLOCK;
         int first = 0, last = 0;
-        if (XTILE && myLen[j] > 0) {
+        if (XTILE && !PLAN && myLen[j] > 0) {
             first = a.rP[(long long)myBase[j]];
             last = a.rP[(long long)myBase[j] + (long long)(myLen[j] - 1) * a.idxStride];
         }
         /* depth of the 32-row sub-group these 32 lanes hold; the deep ones register and are cut at deepCap */
         const int depth = halfReduce(myLen[j], MaxOf{});
-        int slot = -1;
-        if constexpr (DEEP) {
-            if ((lane & 31) == 0 && depth > a.deepCap && i < ROWS)
+        /* Who works the sub-group off.  kHere: this workgroup's stream (a sub-group registered in the deep list: its first
+         * deepKeep columns).  kElsewhere: a workgroup of deep sub-groups, as the plan says.  kBehind: this workgroup, behind its
+         * stream, whole (deep_rows.hip.h) -- deeper than the cap with nobody else to take it: a stale or absent plan, a
+         * full list.  The chunks and their order are the same in all three. */
+        int slot = -1, who = kHere;
+        const bool deep = DEEP && depth > a.deepCap;
+        if constexpr (PLAN) {
+            const bool listed = ((planned.deepMask >> ((i >> 5) & 63)) & 1ull) != 0ull;
+            who = listed ? kElsewhere : (deep ? kBehind : kHere);
+            if (listed != deep && (lane & 31) == 0 && i < ROWS && blockRow0 + i < a.rows && a.planFlags)
+                a.planFlags[1] = 1; /* the plan is of another matrix: the host retires it before its next call */
+        } else if constexpr (DEEP) {
+            if ((lane & 31) == 0 && deep && i < ROWS)
                 slot = deepRegister(a, (int)(blockRow0 + i), depth, myBase[j]);
             const int slotLow = __builtin_amdgcn_readlane(slot, 0), slotHigh = __builtin_amdgcn_readlane(slot, 32);
             slot = (lane & 32) ? slotHigh : slotLow;
+            who = (BEHIND && deep && slot < 0) ? kBehind : kHere;
         }
+        stagedHere[j] = who == kHere && slot < 0;
         if (i < ROWS) {
-            const int walked = (slot >= 0 && myLen[j] > a.deepKeep) ? a.deepKeep : myLen[j];
+            const int walked = who != kHere ? 0 : ((slot >= 0 && myLen[j] > a.deepKeep) ? a.deepKeep : myLen[j]);
             lens[i] = (unsigned short)(walked < 0xFFFF ? walked : 0xFFFF);
             if constexpr (!ZSTAGE)
                 dests[i] = myDest[j];
             if (i % RPL == 0)
                 bases[i / RPL] = myBase[j];
             if ((lane & 31) == 0) {
-                depths[i >> 5] = slot >= 0 ? a.deepKeep : depth;
-                deepSlots[i >> 5] = slot;
+                depths[i >> 5] = who != kHere ? -who : (slot >= 0 ? a.deepKeep : depth); /* < 0: not walked by this stream */
+                deepSlots[i >> 5] = who != kHere ? -2 : slot; /* -1: finished here (staged or stored); >= 0: the deep kernels finish it */
             }
         }
-        if (XTILE && myLen[j] > 0) {
+        if (XTILE && !PLAN && myLen[j] > 0) {
             const int f = first - a.baseIndex, l = last - a.baseIndex;
             const int low = f < l ? f : l, high = f < l ? l : f;
             mine.lowest = low < mine.lowest ? low : mine.lowest;
@@ -194,7 +260,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
             mine.rows += 1;
         }
     }
-    if constexpr (XTILE) {
+    if constexpr (XTILE && !PLAN) {
         mine.lowest = waveReduce(mine.lowest, MinOf{});
         mine.highest = waveReduce(mine.highest, MaxOf{});
         mine.rows = waveReduce(mine.rows, SumOf{});
@@ -210,7 +276,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
             const int i = threadIdx.x + j * BLOCK;
-            if (i < ROWS && blockRow0 + i < a.rows)
+            if (i < ROWS && blockRow0 + i < a.rows && stagedHere[j])
                 low = myDest[j] < low ? myDest[j] : low;
         }
         low = waveReduce(low, MinOf{});
@@ -228,7 +294,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
             if (i < ROWS) {
                 const long long off = (long long)myDest[j] - zBase;
                 /* (rows of a deep sub-group are finished by the deep kernels: nothing of theirs is staged) */
-                const bool in = blockRow0 + i < a.rows && off >= 0 && off < ZW && !(DEEP && deepSlots[i >> 5] >= 0);
+                const bool in = blockRow0 + i < a.rows && off >= 0 && off < ZW && stagedHere[j];
                 destOffset[i] = in ? (unsigned short)off : (unsigned short)0xFFFF;
                 if (in)
                     atomicOr(&stagedMask[off >> 5], 1u << (off & 31));
@@ -247,7 +313,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     const int split = a.split;
     const int myDepthHere = lane < SUBS ? depths[lane] : 0;
     const bool mySplit = split > 0 && myDepthHere > split && myDepthHere <= a.deepCap;
-    const int myChunks = lane < SUBS ? (mySplit ? (myDepthHere + split - 1) / split : 1) : 0;
+    const int myChunks = lane < SUBS ? (mySplit ? (myDepthHere + split - 1) / split : ((BEHIND && myDepthHere < 0) ? 0 : 1)) : 0;
     /* inclusive prefix sums over the lanes by counting bits: a sub-group has at most kRaggedMostChunks chunks, "lane l has at least
      * K chunks" is one ballot per K, and the bits of it below a lane are one mbcnt (no cross-lane data movement at all) */
     int itemIncl = myChunks, parkIncl = mySplit ? myChunks : 0, totalItems = 0, totalParks = 0;
@@ -268,7 +334,8 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         subFacts[lane] = int2{itemIncl - myChunks, mySplit ? parkIncl - myChunks : -1};
     /* first parked chunk sum + 1 (0: one chunk) in the top 10 bits, the walked depth below: what loadItem asks lane s for */
     static_assert(SUBS * kRaggedMostChunks<T> < 1023, "a park number fits 10 bits");
-    const int parkAndDepth = (int)(((unsigned)(mySplit ? parkIncl - myChunks + 1 : 0) << 22) | (unsigned)(myDepthHere < 0x3FFFFF ? myDepthHere : 0x3FFFFF));
+    const int parkAndDepth = (int)(((unsigned)(mySplit ? parkIncl - myChunks + 1 : 0) << 22) |
+                                   (unsigned)(myDepthHere < 0x3FFFFF ? ((BEHIND && myDepthHere < 0) ? 0 : myDepthHere) : 0x3FFFFF));
     const unsigned long long splitOnes = __ballot(mySplit);
 
     struct Item {
@@ -393,12 +460,16 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     if constexpr (XTILE) {
         /* the wavefronts' probes meet: a lane reads ONE of them, the rest is DPP (every lane reading all WAVES of them was
          * 24 LDS reads per lane behind the neighbour's traffic) */
-        const ColumnProbe one = lane < WAVES ? seen[lane] : ColumnProbe{0x7fffffff, -0x7fffffff - 1, 0, 0};
         ColumnProbe all;
-        all.lowest = waveReduce(one.lowest, MinOf{});
-        all.highest = waveReduce(one.highest, MaxOf{});
-        all.rows = waveReduce(one.rows, SumOf{});
-        all.middles = (long long)waveSumExact((double)one.middles);
+        if constexpr (PLAN) {
+            all = ColumnProbe{planned.lowest, planned.highest, planned.probed, (long long)planned.middle * planned.probed};
+        } else {
+            const ColumnProbe one = lane < WAVES ? seen[lane] : ColumnProbe{0x7fffffff, -0x7fffffff - 1, 0, 0};
+            all.lowest = waveReduce(one.lowest, MinOf{});
+            all.highest = waveReduce(one.highest, MaxOf{});
+            all.rows = waveReduce(one.rows, SumOf{});
+            all.middles = (long long)waveSumExact((double)one.middles);
+        }
         if (all.rows > 0 && all.lowest >= 0) {
             const long long span = (long long)all.highest - all.lowest + 1;
             if (span <= tileRoom) {
@@ -446,7 +517,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         const long long r = blockRow0 + s * 32 + rowInSub;
         if (r >= a.rows)
             return;
-        const int deepSlot = DEEP ? deepSlots[s] : -1;
+        const int deepSlot = (DEEP && !PLAN) ? deepSlots[s] : -1;
         if (deepSlot >= 0) {
             a.deepPartials[(size_t)deepSlot * 32 + (size_t)rowInSub] = rowSum; /* the deep kernels finish the row */
         } else if constexpr (ZSTAGE) {
@@ -569,6 +640,24 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
                 const T v = staged[e];
                 a.z[outRow] = hasBeta ? mulAdd(a.beta, a.y[outRow], v) : v;
             }
+        }
+    }
+    if constexpr (BEHIND) {
+        /* sub-groups deeper than the cap that nobody else takes (stale or absent plan, full list): whole, by this workgroup, in batches */
+        unsigned long long orphans = __ballot(lane < SUBS && depths[lane < SUBS ? lane : 0] == -kBehind);
+        while (orphans != 0ull) { /* workgroup-uniform: every wavefront read the same table */
+            const unsigned long long batch = orphans;
+            int count = __popcll(batch);
+            count = count < kPlanDeepMost ? count : kPlanDeepMost;
+            const int firstSub = (int)logicalBlock * SUBS;
+            wholeSubgroups<T, RPL, IS_HELL, WAVES, TILE_ELEMS * (int)sizeof(T)>(a, tile, count, [&](int j) {
+                unsigned long long rest = batch;
+                for (int skip = 0; skip < j; ++skip)
+                    rest &= rest - 1;
+                return firstSub + __ffsll((long long)rest) - 1;
+            }, false);
+            for (int done = 0; done < count; ++done)
+                orphans &= orphans - 1;
         }
     }
 #ifdef SPGPU_TRACE_BLOCKS

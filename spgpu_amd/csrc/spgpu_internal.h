@@ -19,6 +19,9 @@ extern "C" {
 /* The public struct is the FIRST member, so a spgpuHandle_t is also a pointer
  * to this record. */
 #define SPGPU_DEEP_STREAMS 8
+#define SPGPU_PLANS 8
+#define SPGPU_PLAN_WORDS 4
+#define SPGPU_PLAN_GRAVES 32
 typedef struct SpgpuPrivateHandle {
     SpgpuHandleStruct pub;
     unsigned magic;
@@ -38,8 +41,21 @@ typedef struct SpgpuPrivateHandle {
      * spgpuSetStream: every new one): two SpMVs of one handle in flight on two streams never share a list */
     void* deepScratch[SPGPU_DEEP_STREAMS];
     hipStream_t deepStream[SPGPU_DEEP_STREAMS];
+    hipEvent_t deepIdle[SPGPU_DEEP_STREAMS];  /* recorded behind the deep kernels of the list's latest call: complete = nobody uses the list */
+    int deepUsed[SPGPU_DEEP_STREAMS];         /* the event has been recorded at least once */
+    unsigned deepClock[SPGPU_DEEP_STREAMS];   /* last handed out (the least recently used idle list changes hands) */
+    unsigned deepTick;
     int deepStreams;
+    int deepFallbacks;                        /* ordered SpMV calls on a stream without a list (spgpuDeepListFallbacks) */
+    int deepRecycled;                         /* lists that changed hands (spgpuDeepListsRecycled) */
     int lastSpmvForm;         /* form of the most recent ELL/HELL SpMV launch (diagnostic, atomic) */
+    /* per-matrix plans of the ELL/HELL SpMV with a row order (below; guarded by formLock) */
+    struct SpgpuSpmvPlan* plans;                    /* [SPGPU_PLANS] */
+    int* planPinned;                                /* pinned, SPGPU_PLANS * SPGPU_PLAN_WORDS ints */
+    void* planGraveyard[SPGPU_PLAN_GRAVES];         /* device buffers of retired plans: kernels in flight may still read them */
+    int planGraves;
+    unsigned planClock;
+    int planUses, planBuilds, planStales;           /* diagnostics (spgpuSpmvPlanCounts) */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8 /* + one more group of words behind them for spgpu?SpmvForm, and one for the deep list's overflow report */
 #define SPGPU_FEEDBACK_SAMPLES 4
@@ -83,9 +99,61 @@ typedef struct SpgpuDeepList {
     SpgpuDeepItem* items;    /* [SPGPU_DEEP_ITEMS] */
     void* partials;          /* [SPGPU_DEEP_ENTRIES][32] x 16 bytes: row sums over the columns < deepCap */
     void* itemSums;          /* [SPGPU_DEEP_ITEMS][32] x 16 bytes */
+    hipEvent_t idle;         /* to be recorded behind the kernels that use the list */
 } SpgpuDeepList;
 /* Device pointers of the current stream's list, or SPGPU_UNSUPPORTED when that stream has none. */
 spgpuStatus_t spgpuDeepScratch(spgpuHandle_t h, SpgpuDeepList* list);
+
+/*
+ * The plan of one matrix with a row order (csrc/planned_spmv.hip; the north_star target).  The queue kernel for ordered rows
+ * spends a third of its prologue finding out two things that do not change from call to call: where the slice of x lies that
+ * a block of rows touches (a dependent round trip: the first and last column of every row), and which 32-row sub-groups
+ * are too deep for a block (registered through atomics in a list, worked off by two launches BEHIND the main kernel).  An
+ * analysis pass -- started by the first SpMV that sees the matrix, on its stream, not waited for -- writes both down once:
+ * a 32-byte record per block of SUBS sub-groups, and the list of deep sub-groups, which then get workgroups of their own in the
+ * SAME launch.  Later calls on the same arrays find the plan by its key.
+ *
+ * A plan decides only WHO computes a sub-group and WHERE the LDS tile lies -- never what is read or in which order it is
+ * added: every kernel reads the row lengths, slab bases and destinations of the matrix as it is at the call and derives the
+ * chunks of a sub-group from its true depth.  A plan that has gone stale (another matrix at the same addresses) therefore
+ * still gives the same bits as no plan; the kernels notice (a sub-group's true depth contradicts the plan), say so in a
+ * pinned word, and the next call builds a new one.
+ */
+typedef struct SpgpuPlanBlock {
+    int lowest, highest; /* columns (0-based) the block's rows reach: first and last entry of every row outside deep sub-groups */
+    int middle;          /* mean of (first + last) / 2 over those rows */
+    int probed;          /* how many rows took part (0: no tile) */
+    unsigned long long deepMask; /* bit s: sub-group s of the block is in the deep list */
+    int firstDeep;       /* index of its first entry there */
+    int reserved;
+} SpgpuPlanBlock;
+typedef struct SpgpuSpmvPlan {
+    /* key: the arrays the analysis read, and what it assumed */
+    const void *rP, *rS, *rIdx, *hackOffsets;
+    long long idxStride;
+    int rows, hackSize, baseIndex, maxNnz, deepCap, subs; /* subs: 32-row sub-groups per block */
+    /* state */
+    int state;      /* SPGPU_PLAN_EMPTY ... */
+    int stales;     /* times it was found stale */
+    int uses;       /* launches since it was built */
+    unsigned clock; /* last looked up (least recently used goes first) */
+    int blocks;     /* blocks of `subs` sub-groups */
+    int deep;       /* deep sub-groups (read from pinned[0] once the analysis has completed) */
+    void* device;   /* one allocation: SpgpuPlanBlock[blocks] | int counts[blocks] | int deepSubs[sub-groups] */
+    int* pinned;    /* [0] deep sub-groups, written by the analysis; [1] != 0: a kernel found the plan stale */
+    hipEvent_t built;
+} SpgpuSpmvPlan;
+enum { SPGPU_PLAN_EMPTY = 0, SPGPU_PLAN_BUILDING = 1, SPGPU_PLAN_READY = 2, SPGPU_PLAN_GIVEN_UP = 3 };
+/* The plan table is used with the handle's lock held from the look-up to the launch that reads the plan's arrays (a second
+ * host thread on the handle may retire a plan and free retired buffers only under the same lock, after a device-wide wait). */
+void spgpuPlanLock(spgpuHandle_t h);
+void spgpuPlanUnlock(spgpuHandle_t h);
+/* Lock held.  The record with this key; or, if there is none, the least recently used record, retired and re-keyed
+ * (state EMPTY).  Never NULL once the handle exists (NULL: the handle has no plan table -- its allocation failed). */
+SpgpuSpmvPlan* spgpuPlanRecord(spgpuHandle_t h, const SpgpuSpmvPlan* key);
+/* Lock held.  The plan's device buffer goes to the graveyard (kernels in flight may read it); a full graveyard is emptied
+ * after a device-wide wait.  State EMPTY afterwards. */
+void spgpuPlanRetire(spgpuHandle_t h, SpgpuSpmvPlan* plan);
 
 /* With -DSPGPU_DEBUG every launch is followed by a synchronising error check
  * that prints and exits, as the reference does under -DDEBUG
@@ -121,6 +189,9 @@ typedef struct SpgpuTuning {
     int pipeGroups;  /* 0: one workgroup per CU (tests: fewer, so that small matrices run several blocks per workgroup) */
     int raggedSplit; /* -1: about 96 columns per chunk; 0: sub-groups are never cut; > 0: columns per chunk (rounded up to what LDS can park) */
     int l1Nt;        /* -1: by size */
+    int plan;        /* 1: ordered matrices get a per-matrix plan (planned_spmv.hip); 0: never */
+    int planDeepSpread; /* 30: the deep sub-groups' workgroups are spread over the first 30 % of the grid; 0: all in front; < 0: all behind */
+    int planDeepPerBlock; /* 4: deep sub-groups per such workgroup (1 .. 8) */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);
 

@@ -276,3 +276,37 @@ def test_sweep_form_is_the_one_phase_order(gpu, letter, fmt, n, hack, base):
             assert dz.cpu().numpy().tobytes() == want.tobytes(), (alpha, beta, in_place)
     finally:
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+
+
+@pytest.mark.parametrize("letter", ["D", "C"])
+@pytest.mark.parametrize("hint", [1, 5, 8])
+def test_short_row_hint_same_bits(gpu, letter, hint):
+    """avgNnzPerRow in 1 .. 8 selects the kernel without a prefetch ring for the 8-byte types (ellpack_spmv.hip launchLean; the
+    hint is the reference's own, hell_spmv_base_template.cuh:306-325, and only an average): on rows of 0 .. 300 entries, empty
+    rows, rows longer than a stage and long enough for the whole-wave tail, HELL and ELL (ELL with maxNnzPerRow <= 16 takes the
+    kernel, the long one keeps the prefetching kernel), beta != 0 and in place -- the bytes of the default kernel (hint 0) and
+    of the oracle in its order."""
+    from spgpu_amd import formats, synth
+    n = 5000 + 3
+    rng = np.random.default_rng(hint + (7 if letter == "C" else 0))
+    for longest in (300, 14):
+        lengths = np.minimum(rng.zipf(1.4, size=n), longest).astype(np.int64)
+        lengths[rng.integers(0, n, 200)] = 0
+        lengths[[1, n // 2, n - 1]] = [longest, longest - 1, longest]
+        _, _, r, c, v = synth.random_rows_coo(n, n, lengths, seed=11 + hint, letter=letter)
+        ell = formats.coo_to_ell(n, r, c, v)
+        hell = formats.ell_to_hell(ell, 32)
+        x, y = synth.values_for(letter, 3, n), synth.values_for(letter, 4, n)
+        for mat, dev in ((hell, formats.DeviceHell(hell)), (ell, formats.DeviceEll(ell))):
+            for alpha, beta, in_place in ((1.0, 0.0, False), (-0.5, 1.5, False), (2.0, -1.0, True)):
+                import torch
+                dx, dy = formats.to_device(x), formats.to_device(y)
+                outs = []
+                for avg in (0, hint):
+                    dz = dy.clone() if in_place else torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+                    dev.spmv(gpu, dz, dz if in_place else (dy if beta != 0 else None), alpha, dx, beta, avg_nnz=avg)
+                    torch.cuda.synchronize()
+                    outs.append(dz.cpu().numpy())
+                want = O.default_spmv(mat, x, y if beta != 0 else None, alpha, beta)
+                assert outs[0].tobytes() == want.tobytes(), (longest, "hell" if mat is hell else "ell", alpha, beta)
+                assert outs[1].tobytes() == want.tobytes(), (longest, "hell" if mat is hell else "ell", alpha, beta, "hint")

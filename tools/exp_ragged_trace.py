@@ -29,21 +29,36 @@ h = formats.coo_to_ordered_hell_device(handle, n, *coo, "D", 32, window, long_ro
 x = synth.device_vector(n, "D", 3)
 z = torch.zeros(n, dtype=torch.float64, device="cuda")
 groups = (n + rows_per_group - 1) // rows_per_group
-trace = torch.zeros(8 * groups + 16, dtype=torch.int64, device="cuda")
+extra = 40000      # workgroups of deep sub-groups behind (or in front of) the blocks of rows when the matrix has a plan
+trace = torch.zeros(8 * (groups + extra) + 16, dtype=torch.int64, device="cuda")
 capi.lib.spgpuDebugSetTrace.argtypes = [C.c_void_p]
 call = lambda: capi.hellspmv["D"](handle, p(z), None, 1.0, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]), p(h["rIdx"]), 32, n,
                                   p(x), 0.0, 0)
-for _ in range(3):
+for _ in range(4):
     call()
-torch.cuda.synchronize()
+    torch.cuda.synchronize()
 trace.zero_()
 torch.cuda.synchronize()
 capi.lib.spgpuDebugSetTrace(p(trace))
 call()
 torch.cuda.synchronize()
 capi.lib.spgpuDebugSetTrace(None)
-t = trace[:8 * groups].view(groups, 8).cpu().numpy().astype(np.float64)
-t0 = t[:, 0].min()
+everything = trace[:8 * (groups + extra)].view(groups + extra, 8).cpu().numpy().astype(np.float64)
+ran = everything[:, 0] > 0
+spread = int(os.environ.get("SPGPU_PLAN_DEEP_SPREAD", "30"))
+deep_blocks = int(ran.sum()) - groups
+print(f"plan counts {capi.plan_counts(handle)}; workgroups that ran: {int(ran.sum())} = {groups} blocks of rows + {deep_blocks} of deep sub-groups (spread {spread})")
+grid = groups + deep_blocks
+stride = 0 if spread < 0 or deep_blocks == 0 else max(1, (grid * min(spread, 100) // 100) // deep_blocks) | 1
+ids = np.arange(grid)
+is_deep = (ids >= groups) if stride == 0 else ((ids % stride == 0) & (ids // stride < deep_blocks))
+t = everything[:grid][~is_deep]
+t0 = everything[ran, 0].min()
+if deep_blocks > 0:
+    d = everything[:grid][is_deep]
+    ds, de = (d[:, 0] - t0) / 100.0, (d[:, 1] - t0) / 100.0
+    print(f"  deep workgroups: start {ds.min():.1f} .. {ds.max():.1f} us, end max {de.max():.1f} us, life min {np.min(de - ds):.1f} median {np.median(de - ds):.1f} "
+          f"p90 {np.percentile(de - ds, 90):.1f} max {np.max(de - ds):.1f} us, slot-time {np.sum(de - ds):.0f} us ({np.sum(de - ds) / 512:.1f} us of the chip)")
 start, end, tiled = (t[:, 0] - t0) / 100.0, (t[:, 1] - t0) / 100.0, (t[:, 2] - t0) / 100.0
 span = end.max()
 life, prologue = end - start, tiled - start

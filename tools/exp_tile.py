@@ -79,6 +79,8 @@ def run(h, label, forms):
     r_idx = h.get("rIdx")
     if os.environ.get("EXP_IDENTITY_RIDX") and r_idx is not None:      # timing only: same kernel, z written in row order
         r_idx = torch.arange(rows, dtype=torch.int32, device="cuda")
+    if os.environ.get("EXP_IDENTITY_FOR_PLAIN") and r_idx is None:     # timing only: rows as they come through the kernels for ordered rows
+        r_idx = torch.arange(rows, dtype=torch.int32, device="cuda")
     call = lambda: capi.hellspmv[letter](handle, p(z), None, one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
                                          None if os.environ.get("EXP_DROP_RIDX") else p(r_idx), 32, rows, p(x), zero, 0)
     for full in forms:
@@ -111,8 +113,36 @@ def run(h, label, forms):
             call()
         stream.synchronize()
         print(f"{letter} {label:46s} {name:10s} slots/nnz {h['slots'] / h['nnz']:.3f}  {t:.4f} ms  {alg / t * 1e-6:7.1f} GB/s  "
-              f"{alg / t * 1e-6 / 8000:.3f} of 8 TB/s  {check(h, form)}", flush=True)
+              f"{alg / t * 1e-6 / 8000:.3f} of 8 TB/s  {check(h, form)}  plans(uses,builds,stales)={capi.plan_counts(handle)}", flush=True)
     capi.spgpuSetSpmvForm(handle, 0)
+    # EXP_SWEEP="SPGPU_PLAN_DEEP_SPREAD=0,30,60;SPGPU_PLAN_DEEP_PER_BLOCK=2,4": every combination on THIS matrix in THESE allocations
+    # (the time of a kernel moves by several per cent with the placement of the arrays: A/B only inside one process), round-robin,
+    # EXP_SWEEP_REPS times
+    if os.environ.get("EXP_SWEEP"):
+        import itertools
+        knobs = [(part.split("=")[0], part.split("=")[1].split(",")) for part in os.environ["EXP_SWEEP"].split(";")]
+        combos = list(itertools.product(*[values for _, values in knobs]))
+        seen = {c: [] for c in combos}
+        for rep in range(int(os.environ.get("EXP_SWEEP_REPS", "3"))):
+            for combo in combos:
+                for (name, _), value in zip(knobs, combo):
+                    os.environ[name] = value
+                capi.spgpuTuningReload()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(stream):
+                    for _ in range(3):
+                        call()
+                        stream.synchronize()
+                    a.record(stream)
+                    for _ in range(20):
+                        call()
+                    b.record(stream)
+                b.synchronize()
+                seen[combo].append(a.elapsed_time(b) / 20)
+        for combo in combos:
+            ts = seen[combo]
+            print(f"    sweep {label[:40]:40s} " + " ".join(f"{n}={v}" for (n, _), v in zip(knobs, combo)) + "  " + " ".join(f"{t:.4f}" for t in ts)
+                  + f"  median {sorted(ts)[len(ts) // 2]:.4f} ms = {alg / sorted(ts)[len(ts) // 2] * 1e-6 / 8000:.3f}", flush=True)
 
 
 if "uniform" in cases:
