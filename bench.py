@@ -52,6 +52,8 @@ def parse():
                         "one is measured in the same process and reported under `variants`")
     p.add_argument("--driver", default="c", choices=["c", "torch"],
                    help="spmm: who issues a step -- libspgpu.so's sharded driver (RCCL through dlopen), or torch.distributed")
+    p.add_argument("--placements", type=int, default=3,
+                   help="north_star target: how many placements of the matrix' arrays (allocations of their own, one hipMalloc each) are timed")
     p.add_argument("--no-split", action="store_true",
                    help="spmm: do not cut the local block by column ownership (no compute/all-gather overlap)")
     return p.parse_args()
@@ -232,6 +234,45 @@ def cpu_baseline(h, x, seconds):
                                              note="reference ell.c:39-80 + hell.c:46-104 and hdia.cpp:230-324, one thread, as the reference runs them"))
 
 
+class OwnAllocations:
+    """The device arrays of a matrix (and x, z) copied into allocations of their own, one hipMalloc each -- how a C caller of the
+    reference holds them (hellPerf.cpp:176-190: one cudaMalloc per array).  The arrays that come out of this harness' conversion
+    pipeline sit inside blocks of torch's caching allocator instead, and WHERE the arrays of a matrix lie moves the time of a
+    memory-bound kernel on this hardware by several per cent (tools/exp_alloc.py: the same kernel on the same data in one
+    process, 0.68 ... 0.76 ms from one set of allocations to the next) -- so the target is timed on
+    several such placements and the record carries all of them."""
+
+    def __init__(self, tensors):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.ptr = {}
+        for name, t in tensors.items():
+            p, size = C.c_void_p(), t.numel() * t.element_size()
+            if self.hip.hipMalloc(C.byref(p), C.c_size_t(size)) != 0 or self.hip.hipMemcpy(p, C.c_void_p(t.data_ptr()), C.c_size_t(size), 3) != 0:
+                self.free()
+                raise MemoryError(f"hipMalloc / hipMemcpy of {size} bytes for {name}")
+            self.ptr[name] = p
+
+    def __getitem__(self, name):
+        return self.ptr[name]
+
+    def free(self):
+        for p in self.ptr.values():
+            self.hip.hipFree(p)
+        self.ptr = {}
+
+
+def timed_blocks(stream, call, blocks=3, launches=20):
+    """ms per launch of `blocks` timed blocks of `launches` back-to-back launches, after the settling calls"""
+    with __import__("torch").cuda.stream(stream):
+        settle(stream, call, 4)
+    return [time_launches(stream, call, launches) / launches * 1e3 for _ in range(blocks)]
+
+
+def spread(values):
+    v = sorted(values)
+    return dict(min=round(v[0], 4), median=round(v[len(v) // 2], 4), max=round(v[-1], 4))
+
+
 def check_windows(h, x, z, letter, shape, windows=3, rows=2048):
     """Parity at full size for ANY device HELL dict (ragged, ordered through rIdx or not): `windows` hack-aligned row
     windows of the device result against the oracle run in the kernel's summation order (`shape`: the spmv_tail
@@ -269,7 +310,11 @@ def bench_powerlaw(args, handle, stream, dev, rows):
     z = torch.zeros(rows, dtype=torch.float64, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     out = dict(rows=rows, mean_len=round(float(lengths.mean()), 2), max_len=int(lengths.max()),
-               order="spgpuOellOrderDevice(window=2048, longRows=256) + spgpuCooPermuteRowsDevice + spgpuCooToHellDevice")
+               order="spgpuOellOrderDevice(window=2048, longRows=256) + spgpuCooPermuteRowsDevice + spgpuCooToHellDevice",
+               timing="ordered layouts: ms = median over `placements` (the matrix' arrays, x and z in allocations of their own, one hipMalloc "
+                      "each as hellPerf.cpp:176-190 holds them; 3 timed blocks of 20 launches per placement, each block listed) -- "
+                      "as_built_ms: the arrays as this harness' pipeline leaves them inside torch's allocator; the placement of the arrays "
+                      "moves a memory-bound kernel by several per cent on this hardware (tools/exp_alloc.py)")
     # the first ordering of a process pays rocPRIM's and the allocator's cold start (1.2 s measured): not the build time
     warm = synth.ragged_coo_on_device(lengths[:4096], 4096, "near", 2048, letter, seed=5, device=dev)
     formats.coo_to_ordered_hell_device(handle, 4096, *warm, letter, 32, 2048, 256, order=True)
@@ -283,10 +328,13 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             except Exception as error:  # noqa: BLE001
                 out[f"{pattern}_vendor_context"] = repr(error)
         # "sorted_aligned": spgpuOellOrderAlignedDevice -- every window of the order is one 2 048-row workgroup (include/spgpu/ell_conv.h)
-        for name, ordered in ({"band": (("sorted", True), ("sorted_aligned", True)), "near": (("plain", False), ("sorted", True), ("sorted_aligned", True)),
+        # "sorted_global": the reference's own order -- ellToOell, ONE sort of all rows by length (ell.c:85-202, hellPerf.cpp:333-378)
+        for name, ordered in ({"band": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True)),
+                               "near": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True)),
                                "random": (("plain", False), ("sorted", True))}[pattern]):
             t0 = time.perf_counter()
-            h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, 2048, 256, order=ordered, aligned=name.endswith("aligned"))
+            window, long_rows = (0, 0) if name == "sorted_global" else (2048, 256)
+            h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, window, long_rows, order=ordered, aligned=name.endswith("aligned"))
             build_s = time.perf_counter() - t0
             # form AUTO throughout: through rIdx the tile form falls back to gathers column by column, and on scattered
             # columns it runs within 1 % of the plain gather form (tools/exp_tile.py, ragged0 vs raggedg)
@@ -294,8 +342,23 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             call = lambda: capi.hellspmv[letter](handle, p(z), None, C.c_double(1.0), p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]),
                                                  p(h["rS"]), p(h["rIdx"]), 32, rows, p(x), C.c_double(0.0), 0)
             with torch.cuda.stream(stream):
-                settle(stream, call)
-            t = time_launches(stream, call, 20) / 20
+                settle(stream, call, 4)
+            as_built = [time_launches(stream, call, 20) / 20 * 1e3 for _ in range(3)]
+            t = sorted(as_built)[1] * 1e-3
+            placements = None
+            if ordered and pattern != "random" and name != "sorted_global" and args.placements > 0:
+                placements = []
+                for _ in range(args.placements):
+                    own = OwnAllocations(dict(cM=h["cM"], rP=h["rP"], hack_offsets=h["hack_offsets"], rS=h["rS"], rIdx=h["rIdx"], x=x, z=z))
+                    try:
+                        torch.cuda.synchronize()
+                        placed = lambda own=own: capi.hellspmv[letter](handle, own["z"], None, C.c_double(1.0), own["cM"], own["rP"], 32, own["hack_offsets"],
+                                                                       own["rS"], own["rIdx"], 32, rows, own["x"], C.c_double(0.0), 0)
+                        placements.append(timed_blocks(stream, placed))
+                    finally:
+                        torch.cuda.synchronize()
+                        own.free()
+                t = sorted(sorted(blocks)[len(blocks) // 2] for blocks in placements)[len(placements) // 2] * 1e-3
             z.zero_()
             torch.cuda.synchronize()
             time_launches(stream, call, 1)
@@ -308,7 +371,16 @@ def bench_powerlaw(args, handle, stream, dev, rows):
                                             gflops=round(2.0 * h["nnz"] / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
                                             frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), algorithmic_bytes=alg,
                                             hell_GB=round(h["slots"] * (elem + 4) * 1e-9, 2), build_ms=round(build_s * 1e3, 1), form=ran,
-                                            parity=check_windows(h, x, z, letter, shape))
+                                            parity=check_windows(h, x, z, letter, shape), as_built_ms=[round(v, 4) for v in as_built])
+            if placements:
+                entry = out[f"{pattern}_{name}"]
+                entry["placements_ms"] = [[round(v, 4) for v in blocks] for blocks in placements]
+                every = [v for blocks in placements for v in blocks]
+                entry["ms_spread"] = spread(every)
+                entry["frac_spread"] = {k: round(alg / (v * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4) for k, v in (("best", min(every)), ("worst", max(every)))}
+            if ordered:
+                entry = out[f"{pattern}_{name}"]
+                entry["plan_counts_uses_builds_stales"] = list(capi.plan_counts(handle))
             del h
             torch.cuda.empty_cache()
         del coo
@@ -540,6 +612,16 @@ def run_spmv(args, rank, world):
     flops = 2.0 * h["nnz"]
     alg = hell_algorithmic_bytes(h["nnz"], h["rows"], h["cols"], hacks)
     per_launch = kernel_s / args.steps
+    # the same launches once more in five blocks, with what the card reports about itself sampled beside them: a memory-bound
+    # kernel on this pool runs at speeds several per cent apart from card to card and from one set of allocations to the next
+    #  -- the record says which card, in which state, and how much the blocks differ
+    from spgpu_amd import gpu_state
+    card = gpu_state.Card(torch.cuda.current_device())
+    with gpu_state.Sampler(card) as sampler:
+        blocks = [time_launches(stream, step, max(args.steps // 5, 10)) / max(args.steps // 5, 10) * 1e3 for _ in range(5)]
+    device = dict(card.identity(), name=torch.cuda.get_device_name(dev), during_timed_blocks=sampler.summary(),
+                  note="sysfs of the card as this container sees it (clocks / power sampled every 4 ms during the five blocks; inside this "
+                       "pool's containers the busy counters read 0 and the clock files do not follow the load: recorded for what they are worth)")
     out = dict(
         metric="HELL fp64 SpMV GFLOP/s + achieved HBM GB/s (% of roofline), 1 GPU",
         value=round(flops * args.steps * world / wall * 1e-9, 2), unit="GFLOP/s", n_gpus=world,
@@ -554,7 +636,8 @@ def run_spmv(args, rank, world):
                       traffic=committed_traffic(h["rows"], args.nnz_per_row, args.pattern),
                       kernel=f"slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, prefetch after gathers, tail> in the form "
                              f"spgpuGetLastSpmvForm reports: {headline_form}", algorithmic_bytes_per_launch=alg,
-                      kernel_ms=round(per_launch * 1e3, 5)),
+                      kernel_ms=round(per_launch * 1e3, 5), kernel_ms_blocks=spread(blocks)),
+        device=device,
     )
 
     if rank == 0:
@@ -647,12 +730,14 @@ def run_spmv(args, rank, world):
                 torch.cuda.empty_cache()
             out["configs"] = configs
             pl = configs.get("powerlaw_fp64", {})
-            target = {name: dict(ms=pl[name]["ms"], frac=pl[name]["frac"], slots_per_nnz=pl[name]["slots_per_nnz"], parity=pl[name]["parity"])
-                      for name in ("band_sorted", "band_sorted_aligned", "near_sorted", "near_sorted_aligned", "near_plain") if isinstance(pl.get(name), dict)}
+            target = {name: {key: pl[name][key] for key in ("ms", "frac", "frac_spread", "ms_spread", "slots_per_nnz", "parity") if key in pl[name]}
+                      for name in ("band_sorted_aligned", "band_sorted", "near_sorted_aligned", "near_sorted", "band_sorted_global", "band_plain", "near_plain")
+                      if isinstance(pl.get(name), dict)}
             target["what"] = ("north_star target: spgpuDhellspmv, fp64, 10 M rows, power-law lengths (mean 32, max 2048), rows ordered "
                               "on the device (windows of 2048, rows > 256 set aside) and run through rIdx; *_aligned: the order whose windows "
-                              "coincide with the kernel's 2048-row workgroups (spgpuOellOrderAlignedDevice); frac = algorithmic bytes / "
-                              "time / 8 TB/s; bar 0.70")
+                              "coincide with the kernel's 2048-row workgroups (spgpuOellOrderAlignedDevice); *_global: the reference's own order, "
+                              "one sort of all rows (ellToOell, ell.c:85-202); *_plain: the rows as they come, no rIdx; frac = algorithmic bytes / "
+                              "time / 8 TB/s, time = median over placements of the arrays (ms_spread / frac_spread: every timed block); bar 0.70")
             out["config"]["north_star_target"] = target
             out["target"] = target
             if world == 1:
@@ -664,7 +749,7 @@ def run_spmv(args, rank, world):
         elif "cpu_baseline" not in out:
             out["cpu_baseline"] = None
         first = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                 "data", "config", "roofline", "target", "cpu_baseline", "parity"]
+                 "data", "config", "roofline", "target", "cpu_baseline", "parity", "device"]
         out = {**{key: out[key] for key in first if key in out}, **{key: value for key, value in out.items() if key not in first}}
         print(json.dumps(out), flush=True)
     capi.spgpuDestroy(handle)

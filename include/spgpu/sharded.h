@@ -76,9 +76,11 @@ void spgpuCommDestroy(void* comm);
 /* blockFirstRow: world + 1 host entries.  rest may be NULL (or rows == 0) when the block has no foreign columns.
  * comm: the rank's ncclComm_t (any RCCL the process uses), NULL allowed for world == 1.
  * Collective over the communicator for SPGPU_EXCHANGE_NEEDED: every rank must call it.  Synchronises the handle's stream.
- * world <= 960 (SPGPU_UNSUPPORTED beyond).  Failure: the set-up's local steps (allocations, sorting) are followed by an
- * agreement of all ranks before each of its collectives, so a failure on ONE rank makes EVERY rank return an error from
- * this call instead of leaving the others inside a collective; if a send or receive of the row-number exchange cannot be
+ * world <= 960 (SPGPU_UNSUPPORTED beyond).  Failure: every local step -- the check of the row partition against this rank's
+ * block, the plan's host memory, its stream and events, then the set-up's allocations and sorting -- is followed by an
+ * agreement of all ranks before the next collective, so a failure on ONE rank makes EVERY rank return an error from
+ * this call instead of leaving the others inside a collective (the one exception: a rank called without a handle, without
+ * a communicator or with a rank number outside 0 .. world-1 returns at once -- it has nothing to speak through); if a send or receive of the row-number exchange cannot be
  * posted, the communicator is aborted (ncclCommAbort, where the RCCL in use has it) rather than a half-posted group launched
  * -- it must not be used again.  An error inside RCCL itself (a peer that died) is RCCL's to report. */
 spgpuStatus_t spgpuDhellspmmShardedCreate(spgpuShardedSpmm_t* plan, spgpuHandle_t handle, void* comm, int rank, int world,

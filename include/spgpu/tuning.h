@@ -67,8 +67,8 @@ int spgpuDeepListsRecycled(spgpuHandle_t handle);
  * plan that has gone stale (another matrix at the same addresses): a plan decides who computes, never what or in which order.
  * A stale plan is noticed by the kernels and rebuilt by the next call.  Launches captured into a HIP graph never use a plan.
  *   SPGPU_PLAN=0                 no plans
- *   SPGPU_PLAN_DEEP_PER_BLOCK    deep sub-groups per workgroup of theirs (default 4, 1 .. 8)
- *   SPGPU_PLAN_DEEP_SPREAD       those workgroups are spread over the first N per cent of the grid (default 30; 0: all in front;
+ *   SPGPU_PLAN_DEEP_PER_BLOCK    deep sub-groups per workgroup of theirs (default 8, 1 .. 8)
+ *   SPGPU_PLAN_DEEP_SPREAD       those workgroups are spread over the first N per cent of the grid (default 60; 0: all in front;
  *                                -1: all behind the blocks of rows)
  * spgpuSpmvPlanCounts: launches that ran with a plan, analyses started, plans found stale (any pointer may be NULL).
  */

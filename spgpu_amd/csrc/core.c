@@ -237,7 +237,7 @@ size_t spgpuSizeOf(spgpuType_t typeCode)
     }
 }
 
-int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows, int* calls)
+int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows, int* calls, int* tag)
 {
     /* Two host threads may share a handle (the reference documents one handle per thread, core.h:88-90, but does not
      * enforce it): the table is searched and re-assigned under a lock.  The words themselves are written by the GPU
@@ -249,12 +249,15 @@ int* spgpuFormFeedback(spgpuHandle_t pHandle, const void* key, int rows, int* ca
         if (h->formKey[e] == key && h->formRows[e] == rows) {
             slot = h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
             *calls = ++h->formCalls[e];
+            *tag = h->formGeneration[e] << 8;
         }
     if (!slot) {
         const unsigned e = h->formNext++ % SPGPU_FEEDBACK_ENTRIES; /* oldest entry makes room */
         h->formKey[e] = key;
         h->formRows[e] = rows;
         h->formCalls[e] = 0;
+        h->formGeneration[e] = (h->formGeneration[e] + 1) & 0x7FFFFF; /* reports still in flight for the previous owner carry the old one */
+        *tag = h->formGeneration[e] << 8;
         *calls = 0;
         slot = h->formFeedback + e * SPGPU_FEEDBACK_SAMPLES;
         for (int i = 0; i < SPGPU_FEEDBACK_SAMPLES; ++i)
@@ -468,8 +471,8 @@ void spgpuTuningReload(void)
     t.raggedSplit = envInt("SPGPU_RAGGED_SPLIT", -1);
     t.l1Nt = envInt("SPGPU_L1_NT", -1);
     t.plan = envInt("SPGPU_PLAN", 1);
-    t.planDeepSpread = envInt("SPGPU_PLAN_DEEP_SPREAD", 30);
-    t.planDeepPerBlock = envInt("SPGPU_PLAN_DEEP_PER_BLOCK", 4);
+    t.planDeepSpread = envInt("SPGPU_PLAN_DEEP_SPREAD", 60);
+    t.planDeepPerBlock = envInt("SPGPU_PLAN_DEEP_PER_BLOCK", 8);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);
 }

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
                             /* at least half of it as strips -- and more than one stage of it: the test costs about a
                              * third of a stage, which a single stage of strips does not earn back (5-point Laplacian,
                              * 16.7 M rows: 258 us with it, 251 us as gathers) */
-                            a.feedback[q - 1] = 2 * kBase >= groupLongest && groupLongest > STEP ? 2 : other;
+                            a.feedback[q - 1] = a.feedbackTag | (2 * kBase >= groupLongest && groupLongest > STEP ? 2 : other);
                 }
             }
         }
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(kBlockThreads) void deepFinishKernel(const SlabArgs
             if (a.deepOverflow && (registered > SPGPU_DEEP_ENTRIES || handedOut > SPGPU_DEEP_ITEMS)) {
                 a.deepOverflow[1] = registered;
                 a.deepOverflow[2] = handedOut;
-                a.deepOverflow[0] = a.deepOverflow[0] + 1; /* one writer per call, calls of a stream in order */
+                atomicAdd_system(&a.deepOverflow[0], 1); /* the streams of a handle share the word: two of them may overflow at once */
             }
             a.deepHeader[SPGPU_DEEP_HEAD_ENTRIES] = 0;
             a.deepHeader[SPGPU_DEEP_HEAD_ITEMS] = 0;
@@ -836,8 +836,8 @@ __global__ __launch_bounds__(kWave) void formProbeKernel(const SlabArgs<T> a)
     const long long span = __ballot(below) != 0ull ? (1ll << 40) : (highest < lowest ? 0ll : (long long)highest - lowest + 1);
     const int asStrips = firstBad == 0x7fffffff ? groupLongest : firstBad / STEP * STEP; /* whole stages of strips in front */
     if (lane == 0 && a.feedback)
-        a.feedback[blockIdx.x] = (RPL > 1 && 2 * asStrips >= groupLongest && groupLongest > STEP) ? 2
-                                 : (groupLongest > STEP && span <= a.tileSpanLimit ? 3 : 1); /* one stage of rows: no tile */
+        a.feedback[blockIdx.x] = a.feedbackTag | ((RPL > 1 && 2 * asStrips >= groupLongest && groupLongest > STEP) ? 2
+                                                  : (groupLongest > STEP && span <= a.tileSpanLimit ? 3 : 1)); /* one stage of rows: no tile */
 }
 
 /*
@@ -851,7 +851,7 @@ __global__ __launch_bounds__(kWave) void formProbeKernel(const SlabArgs<T> a)
  */
 template <bool IS_HELL>
 __global__ __launch_bounds__(kWave) void orderedProbeKernel(const int* rP, const int* rS, const int* hackOffsets, const int* rIdx, int hackSize,
-                                                           long long idxStride, int maxNnz, int rows, int baseIndex, int* answer)
+                                                           long long idxStride, int maxNnz, int rows, int baseIndex, int* answer, int tag)
 {
     const int lane = threadIdx.x;
     int near = 0, seen = 0;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(kWave) void orderedProbeKernel(const int* rP, const
         blocksAreWindows += high - low < 2048 + 512 ? 1 : 0;
     }
     if (lane == 0)
-        *answer = (blocksSeen > 0 && blocksAreWindows == blocksSeen) ? 6 : (seen > 0 && 4 * near >= 3 * seen) ? 4 : 5;
+        *answer = tag | ((blocksSeen > 0 && blocksAreWindows == blocksSeen) ? 6 : (seen > 0 && 4 * near >= 3 * seen) ? 4 : 5);
 }
 
 /*
@@ -1256,12 +1256,12 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         if (shape == 0 && form != SPGPU_SPMV_FORM_GATHER && a.rIdx != nullptr && sizeof(T) <= 8) {
             /* which of the two product shapes?  (orderedProbeKernel; the answer is kept with AUTO's per-matrix words and
              * read without synchronisation: a first call runs the 1 024-row shape, which is never far off) */
-            int calls = 0;
-            int* seen = spgpuFormFeedback(handle, a.rP, a.rows, &calls);
-            const int said = ((volatile int*)seen)[3];
+            int calls = 0, tag = 0;
+            int* seen = spgpuFormFeedback(handle, a.rP, a.rows, &calls, &tag);
+            const int said = spgpuFeedbackSaid(((volatile int*)seen)[3], tag);
             if (said == 0 || calls % 64 == 0)
                 hipLaunchKernelGGL((orderedProbeKernel<IS_HELL>), dim3(1), dim3(kWave), 0, stream, a.rP, a.rS, a.hackOffsets, a.rIdx, a.hackSize,
-                                   a.idxStride, a.maxNnz, a.rows, a.baseIndex, seen + 3);
+                                   a.idxStride, a.maxNnz, a.rows, a.baseIndex, seen + 3, tag);
             shape = said == 4 || said == 6 ? 4 : 0; /* 6: the blocks are the windows of an aligned order */
         }
         /* a matrix seen before has a plan (planned_spmv.hip): one launch, the deep sub-groups in workgroups of their own, no
@@ -1303,11 +1303,12 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         if (form != SPGPU_SPMV_FORM_AUTO) {
             strips = form == SPGPU_SPMV_FORM_STRIPS;
         } else {
-            int calls = 0;
-            int* seen = spgpuFormFeedback(handle, a.rP, a.rows, &calls);
+            int calls = 0, tag = 0;
+            int* seen = spgpuFormFeedback(handle, a.rP, a.rows, &calls, &tag);
+            a.feedbackTag = tag;
             int gathers = 0, local = 0;
             for (int q = 0; q < 3; ++q) {
-                const int said = ((volatile int*)seen)[q];
+                const int said = spgpuFeedbackSaid(((volatile int*)seen)[q], tag);
                 gathers += said == 1 ? 1 : 0;
                 local += said == 3 ? 1 : 0;
             }
@@ -1423,6 +1424,11 @@ static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     a.idxStride = hackSize;
     a.wideIO = 0;
     a.avgNnzPerRow = avgNnzPerRow;
+    a.feedbackTag = 0;
+    a.planBlocks = nullptr;
+    a.planDeepSubs = nullptr;
+    a.planFlags = nullptr;
+    a.planDeep = a.planMainBlocks = a.planDeepPerBlock = a.planDeepStride = 0;
     launchSlabFamily<T, true>(handle, a);
     spgpuDebugCheck(handle, "hellspmv");
 }
@@ -1452,6 +1458,11 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
     a.idxStride = rPPitch;
     a.wideIO = 0;
     a.avgNnzPerRow = avgNnzPerRow;
+    a.feedbackTag = 0;
+    a.planBlocks = nullptr;
+    a.planDeepSubs = nullptr;
+    a.planFlags = nullptr;
+    a.planDeep = a.planMainBlocks = a.planDeepPerBlock = a.planDeepStride = 0;
     launchSlabFamily<T, false>(handle, a);
     spgpuDebugCheck(handle, "ellspmv");
 }
@@ -1520,6 +1531,7 @@ static int analyseForm(spgpuHandle_t handle, const int* rP, int hackSize, const 
     int* seen = spgpuAnalyseWords(handle);
     seen[0] = seen[1] = seen[2] = 0;
     a.feedback = seen;
+    a.feedbackTag = 0;
     const bool wide = IS_HELL ? (hackSize > 0 && hackSize % WIDE == 0) : true;
     launchFormProbe<T, IS_HELL>(handle->currentStream, a, wide);
     if (hipStreamSynchronize(handle->currentStream) != hipSuccess)

@@ -488,45 +488,61 @@ spgpuStatus_t spgpuDhellspmmShardedCreate(spgpuShardedSpmm_t* plan, spgpuHandle_
         return SPGPU_UNSUPPORTED;
     if (world > 1 && (!comm || !loadRccl()))
         return SPGPU_UNSUPPORTED;
+    /* From here on a rank that fails says so to the others before anyone enters a collective of the needed-rows set-up
+     * (everyRankOk): what can go wrong locally -- a row partition that does not fit this rank's block, host memory, the stream and
+     * the events -- is folded into one status, agreed on ONCE before setUpNeeded, and setUpNeeded agrees again before each of its
+     * own collectives.  (Only the checks above return without a word: a rank without a handle, a communicator or a sane rank
+     * number has nothing to speak through.) */
+    spgpuStatus_t status = SPGPU_SUCCESS;
     for (int r = 0; r < world; ++r)
         if (blockFirstRow[r + 1] < blockFirstRow[r])
-            return SPGPU_UNSPECIFIED;
+            status = SPGPU_UNSPECIFIED;
     if (blockFirstRow[rank + 1] - blockFirstRow[rank] != own->rows || (rest && rest->rows > 0 && rest->rows != own->rows))
-        return SPGPU_UNSPECIFIED;
+        status = SPGPU_UNSPECIFIED;
 
-    spgpuShardedSpmm_t p = (spgpuShardedSpmm_t)calloc(1, sizeof(spgpuShardedSpmmPlan));
-    if (!p)
-        return SPGPU_OUTOFMEMORY;
-    p->handle = handle;
-    p->comm = (ncclComm_t)comm;
-    p->rank = rank;
-    p->world = world;
-    p->count = count;
-    p->exchange = exchange;
-    p->own = *own;
-    p->hasRest = rest && rest->rows > 0 && rest->slots > 0;
-    if (p->hasRest)
-        p->rest = *rest;
-    p->blockFirst = (long long*)malloc((world + 1) * sizeof(long long));
-    p->want = (long long*)calloc(world + 1, sizeof(long long));
-    p->give = (long long*)calloc(world + 1, sizeof(long long));
-    if (!p->blockFirst || !p->want || !p->give) {
-        freePlan(p);
-        return SPGPU_OUTOFMEMORY;
-    }
-    memcpy(p->blockFirst, blockFirstRow, (world + 1) * sizeof(long long));
-    p->equalBlocks = true;
-    for (int r = 1; r < world; ++r)
-        p->equalBlocks = p->equalBlocks && (blockFirstRow[r + 1] - blockFirstRow[r] == blockFirstRow[1] - blockFirstRow[0]);
-
+    spgpuShardedSpmm_t p = status == SPGPU_SUCCESS ? (spgpuShardedSpmm_t)calloc(1, sizeof(spgpuShardedSpmmPlan)) : nullptr;
+    if (!p && status == SPGPU_SUCCESS)
+        status = SPGPU_OUTOFMEMORY;
     int previous = 0;
     (void)hipGetDevice(&previous);
     (void)hipSetDevice(handle->device);
-    spgpuStatus_t status = SPGPU_SUCCESS;
-    if (!hipOk(hipStreamCreateWithFlags(&p->commStream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hipOk(hipEventCreateWithFlags(&p->ready, hipEventDisableTiming), "hipEventCreate") ||
-        !hipOk(hipEventCreateWithFlags(&p->landed, hipEventDisableTiming), "hipEventCreate"))
-        status = SPGPU_UNSPECIFIED;
+    if (p) {
+        p->handle = handle;
+        p->comm = (ncclComm_t)comm;
+        p->rank = rank;
+        p->world = world;
+        p->count = count;
+        p->exchange = exchange;
+        p->own = *own;
+        p->hasRest = rest && rest->rows > 0 && rest->slots > 0;
+        if (p->hasRest)
+            p->rest = *rest;
+        p->blockFirst = (long long*)malloc((world + 1) * sizeof(long long));
+        p->want = (long long*)calloc(world + 1, sizeof(long long));
+        p->give = (long long*)calloc(world + 1, sizeof(long long));
+        if (!p->blockFirst || !p->want || !p->give) {
+            status = SPGPU_OUTOFMEMORY;
+        } else {
+            memcpy(p->blockFirst, blockFirstRow, (world + 1) * sizeof(long long));
+            p->equalBlocks = true;
+            for (int r = 1; r < world; ++r)
+                p->equalBlocks = p->equalBlocks && (blockFirstRow[r + 1] - blockFirstRow[r] == blockFirstRow[1] - blockFirstRow[0]);
+            if (!hipOk(hipStreamCreateWithFlags(&p->commStream, hipStreamNonBlocking), "hipStreamCreate") ||
+                !hipOk(hipEventCreateWithFlags(&p->ready, hipEventDisableTiming), "hipEventCreate") ||
+                !hipOk(hipEventCreateWithFlags(&p->landed, hipEventDisableTiming), "hipEventCreate"))
+                status = SPGPU_UNSPECIFIED;
+        }
+    }
+    if (exchange == SPGPU_EXCHANGE_NEEDED && world > 1) {
+        /* the first agreement: through a stand-in plan, so that a rank whose own plan could not even be allocated takes part */
+        spgpuShardedSpmmPlan voice{};
+        voice.handle = handle;
+        voice.comm = (ncclComm_t)comm;
+        voice.rank = rank;
+        voice.world = world;
+        if (!everyRankOk(&voice, status == SPGPU_SUCCESS) && status == SPGPU_SUCCESS)
+            status = SPGPU_UNSPECIFIED; /* another rank failed: nobody goes on */
+    }
     if (status == SPGPU_SUCCESS) {
         if (exchange == SPGPU_EXCHANGE_NEEDED) {
             status = setUpNeeded(p);
@@ -538,7 +554,8 @@ spgpuStatus_t spgpuDhellspmmShardedCreate(spgpuShardedSpmm_t* plan, spgpuHandle_
     }
     (void)hipSetDevice(previous);
     if (status != SPGPU_SUCCESS) {
-        freePlan(p);
+        if (p)
+            freePlan(p);
         return status;
     }
     *plan = p;

@@ -27,6 +27,7 @@ template <typename T> struct SlabArgs {
     int wideIO;   /* y and z are aligned for RPL-wide access */
     int tailLanes; /* TAIL kernels: switch to whole-wave rows when <= this many lanes are busy */
     int* feedback; /* pinned host ints the sample wavefronts report the form they saw to, or NULL */
+    int feedbackTag; /* or-ed into every report: the generation of the table entry the report is for (spgpuFormFeedback) */
     long long tileSpanLimit; /* a sample group whose columns span at most this many counts as "local" (x-tile form) */
     /* DEEP kernels: 32-row sub-groups deeper than deepCap hand their columns >= deepCap to the deep kernels */
     int deepCap;

@@ -34,6 +34,7 @@ typedef struct SpgpuPrivateHandle {
     const void* formKey[8];
     int formRows[8];
     int formCalls[8];                               /* SpMV calls seen for the entry */
+    int formGeneration[8];                          /* bumped when the entry is given to another matrix (tags the reports) */
     unsigned formNext;
     pthread_mutex_t formLock; /* guards formKey / formRows / formNext */
     int spmvForm;             /* SPGPU_SPMV_FORM_* set by spgpuSetSpmvForm (atomic) */
@@ -165,7 +166,13 @@ void spgpuNoteSpmvForm(spgpuHandle_t h, int form);
 
 /* The feedback ints of the matrix identified by (key, rows): found or newly assigned (and zeroed); *calls = how many
  * SpMV calls have asked for this entry before. */
-int* spgpuFormFeedback(spgpuHandle_t h, const void* key, int rows, int* calls);
+int* spgpuFormFeedback(spgpuHandle_t h, const void* key, int rows, int* calls, int* tag);
+/* A report is (generation of the table entry << 8) | answer.  A probe queued for a matrix whose entry has meanwhile been
+ * given to another matrix lands in that matrix' words with the OLD generation: read as "nothing said" (0). */
+static inline int spgpuFeedbackSaid(int word, int tag)
+{
+    return (word & ~0xFF) == tag ? (word & 0xFF) : 0;
+}
 
 /* Environment knobs (include/spgpu/tuning.h), read once and cached: no getenv in a launch path. */
 typedef struct SpgpuTuning {
@@ -190,8 +197,8 @@ typedef struct SpgpuTuning {
     int raggedSplit; /* -1: about 96 columns per chunk; 0: sub-groups are never cut; > 0: columns per chunk (rounded up to what LDS can park) */
     int l1Nt;        /* -1: by size */
     int plan;        /* 1: ordered matrices get a per-matrix plan (planned_spmv.hip); 0: never */
-    int planDeepSpread; /* 30: the deep sub-groups' workgroups are spread over the first 30 % of the grid; 0: all in front; < 0: all behind */
-    int planDeepPerBlock; /* 4: deep sub-groups per such workgroup (1 .. 8) */
+    int planDeepSpread; /* 60: the deep sub-groups' workgroups are spread over the first 60 % of the grid; 0: all in front; < 0: all behind */
+    int planDeepPerBlock; /* 8: deep sub-groups per such workgroup (1 .. 8) */
 } SpgpuTuning;
 const SpgpuTuning* spgpuTuning(void);
 

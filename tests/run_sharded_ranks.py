@@ -49,11 +49,13 @@ def rank_main(rank):
         comm = C.c_void_p()
         assert capi.spgpuCommInitRank(C.byref(comm), world, ident, rank) == capi.SPGPU_SUCCESS
         firsts = (C.c_longlong * (world + 1))(*[int(v) for v in first])
+        if os.environ.get("SPGPU_TEST_BAD_PARTITION_RANK") == str(rank):
+            firsts[rank + 1] += 32      # this rank is told a row partition that does not fit its own block: Create fails BEFORE the set-up
         ob, rb = capi.hell_block(own, L), capi.hell_block(rest, L)
         plan = capi.ShardedPlan()
         kind = capi.EXCHANGE_NEEDED if exchange == "needed" else capi.EXCHANGE_ALLGATHER
         status = capi.spgpuDhellspmmShardedCreate(C.byref(plan), handle, comm, rank, world, firsts, C.byref(ob), C.byref(rb), k, kind)
-        if os.environ.get("SPGPU_TEST_FAIL_SETUP_RANK"):
+        if os.environ.get("SPGPU_TEST_FAIL_SETUP_RANK") or os.environ.get("SPGPU_TEST_BAD_PARTITION_RANK"):
             # one rank's local set-up is made to fail: EVERY rank must come back from Create with an error (none may hang)
             results[rank] = (status != capi.SPGPU_SUCCESS, f"rank {rank}: Create returned {status} (a peer's set-up failed)")
             capi.spgpuCommDestroy(comm)

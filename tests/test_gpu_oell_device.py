@@ -576,180 +576,6 @@ def test_more_streams_than_deep_lists(gpu):
 
 
 @pytest.mark.parametrize("pattern,expect", [("banded", "strips"), ("near512", "xtile"), ("random", "gather")])
-def test_auto_form_settles_on_the_matrix(gpu, pattern, expect):
-    """AUTO: sample wavefronts of every launch report what they saw and the next launch on the same arrays uses it --
-    consecutive columns -> strips, columns inside a window an LDS tile holds -> x-tile, scattered -> gathers.  The sums
-    do not depend on the form (uniform rows: every shape adds a row's products in ascending k)."""
-    import torch
-    from spgpu_amd import capi, synth
-    n = 400_000
-    h = synth.hell_uniform_on_device(n, 32, pattern, "D", 32, seed=3)
-    x = synth.device_vector(n, "D", 5)
-    z = torch.empty(n, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
-    results = []
-    for _ in range(10):     # the arrays may sit where the previous case's did: the forms that do not report are probed every 4th call
-        capi.hellspmv["D"](gpu, _dp(z), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), None, 32, n,
-                           _dp(x), 0.0, 0)
-        torch.cuda.synchronize()
-        results.append(z.cpu().numpy().tobytes())
-    assert capi.spgpuGetLastSpmvForm(gpu) == {"strips": capi.FORM_STRIPS, "xtile": capi.FORM_XTILE, "gather": capi.FORM_GATHER}[expect]
-    assert len(set(results)) == 1
-    sub = synth.hell_rows_to_host(h, 0, 2048)
-    assert z[:2048].cpu().numpy().tobytes() == O.default_spmv(sub, x.cpu().numpy(), None, 1.0, 0.0).tobytes()
-
-
-def _deep_case(gpu, n, seed):
-    """A matrix whose ordered form has deep sub-groups (rows up to 900 entries, cap 256), as a device HELL + host copy."""
-    import torch
-    from spgpu_amd import formats, synth
-    lengths = np.minimum(synth.power_law_lengths(n, 14.0, 900, seed), 900)
-    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, "near", 450, "D", seed=seed)
-    h = formats.coo_to_ordered_hell_device(gpu, n, rows_t, cols_t, vals_t, "D", 32, 512, 200)
-    sub = dict(letter="D", rows=n, values=h["cM"][:h["slots"]].cpu().numpy(), indices=h["rP"][:h["slots"]].cpu().numpy(),
-               hack_offsets=h["hack_offsets"].cpu().numpy(), hack_size=32, row_lengths=h["rS"][:n].cpu().numpy(), base=0)
-    assert int(h["rS"].max()) > O.DEEP_CAP
-    return h, sub
-
-
-def test_deep_list_in_a_replayed_graph(gpu):
-    """The deep list's header is zeroed by the finish kernel's last workgroup: an SpMV with deep rows captured ONCE and
-    replayed five times (new x every time) gives the oracle's bits every time."""
-    import torch
-    from spgpu_amd import capi, formats, synth
-    n = 9000
-    h, sub = _deep_case(gpu, n, 21)
-    r_idx = h["rIdx"].cpu().numpy()
-    shape_args = O.slab_shape("D", "ragged", deep_cap=O.DEEP_CAP)
-    dx = formats.to_device(synth.values_for("D", 1, n))
-    dz = torch.zeros(n, dtype=torch.float64, device="cuda")
-    call = lambda: capi.hellspmv["D"](gpu, _dp(dz), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]),
-                                      _dp(h["rIdx"]), 14, n, _dp(dx), 0.0, 0)
-    side = torch.cuda.Stream()
-    capi.spgpuSetStream(gpu, C.c_void_p(side.cuda_stream))
-    try:
-        with torch.cuda.stream(side):
-            call()                               # warm-up outside the capture (the stream's list exists since spgpuSetStream)
-        side.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            call()
-        for rep in range(5):
-            x = synth.values_for("D", 100 + rep, n)
-            dx.copy_(formats.to_device(x))
-            torch.cuda.synchronize()
-            graph.replay()
-            torch.cuda.synchronize()
-            want = O.spmv_tail(sub, x, None, 1.0, 0.0, r_idx=r_idx, **shape_args)
-            assert dz.cpu().numpy().tobytes() == want.tobytes(), rep
-    finally:
-        capi.spgpuSetStream(gpu, None)
-
-
-def test_two_handles_on_two_threads_with_deep_rows(gpu):
-    """Every handle owns its deep list: two host threads, a handle and a stream each, 20 SpMVs with deep rows each at the
-    same time -- both get the oracle's bits on every call."""
-    import threading
-    import torch
-    from spgpu_amd import capi, formats, synth
-    cases = []
-    for seed, n in ((31, 7000), (32, 11000)):
-        h, sub = _deep_case(gpu, n, seed)
-        x = synth.values_for("D", seed, n)
-        want = O.spmv_tail(sub, x, None, 1.0, 0.0, r_idx=h["rIdx"].cpu().numpy(), **O.slab_shape("D", "ragged", deep_cap=O.DEEP_CAP))
-        cases.append((h, n, formats.to_device(x), want))
-    torch.cuda.synchronize()
-    failures = []
-
-    def work(case):
-        h, n, dx, want = case
-        handle = capi.create_handle(0)
-        stream = torch.cuda.Stream()
-        capi.spgpuSetStream(handle, C.c_void_p(stream.cuda_stream))
-        dz = torch.zeros(n, dtype=torch.float64, device="cuda")
-        try:
-            for rep in range(20):
-                capi.hellspmv["D"](handle, _dp(dz), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]),
-                                   _dp(h["rIdx"]), 14, n, _dp(dx), 0.0, 0)
-                stream.synchronize()
-                if dz.cpu().numpy().tobytes() != want.tobytes():
-                    failures.append((n, rep))
-                dz.zero_()
-                torch.cuda.synchronize()
-        finally:
-            capi.spgpuSetStream(handle, None)
-            capi.spgpuDestroy(handle)
-
-    threads = [threading.Thread(target=work, args=(case,)) for case in cases]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    assert not failures, failures
-
-
-def test_two_streams_of_one_handle_with_deep_rows(gpu):
-    """The reference's SpMV shares nothing between the streams of a handle (hell_spmv_base_template.cuh:336-345; the caller
-    switches streams with spgpuSetStream, core.c:64-74): two ordered power-law SpMVs queued on two streams of ONE handle,
-    20 rounds without a synchronisation in between, both bit for bit the single-stream result.  Every stream the handle is
-    given owns a deep list."""
-    import torch
-    from spgpu_amd import capi, formats, synth
-    cases = []
-    for seed, n in ((41, 60000), (42, 90000)):
-        h, sub = _deep_case(gpu, n, seed)
-        x = synth.values_for("D", seed, n)
-        want = O.spmv_tail(sub, x, None, 1.0, 0.0, r_idx=h["rIdx"].cpu().numpy(), **O.slab_shape("D", "ragged", deep_cap=O.DEEP_CAP))
-        cases.append((h, n, formats.to_device(x), want, torch.zeros(n, dtype=torch.float64, device="cuda"), torch.cuda.Stream()))
-    torch.cuda.synchronize()
-    try:
-        for rep in range(20):
-            for h, n, dx, want, dz, stream in cases:        # queued back to back: the two calls overlap on the device
-                capi.spgpuSetStream(gpu, C.c_void_p(stream.cuda_stream))
-                capi.hellspmv["D"](gpu, _dp(dz), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]),
-                                   _dp(h["rIdx"]), 14, n, _dp(dx), 0.0, 0)
-            torch.cuda.synchronize()
-            for h, n, dx, want, dz, stream in cases:
-                assert dz.cpu().numpy().tobytes() == want.tobytes(), (n, rep)
-                dz.zero_()
-            torch.cuda.synchronize()
-    finally:
-        capi.spgpuSetStream(gpu, None)
-
-
-def test_more_streams_than_deep_lists(gpu):
-    """A handle keeps a deep list for the first 8 streams it is given; an SpMV on a later stream runs the kernel that needs
-    none (share_spmv.hip.h) -- other order of additions, so compared with the oracle in THAT order -- and stays correct
-    when several of them are in flight."""
-    import torch
-    from spgpu_amd import capi, formats, synth
-    n = 30000
-    handle = capi.create_handle(0)
-    h, sub = _deep_case(handle, n, 51)
-    x = synth.values_for("D", 51, n)
-    r_idx = h["rIdx"].cpu().numpy()
-    with_list = O.spmv_tail(sub, x, None, 1.0, 0.0, r_idx=r_idx, **O.slab_shape("D", "ragged", deep_cap=O.DEEP_CAP))
-    without = O.spmv_tail(sub, x, None, 1.0, 0.0, r_idx=r_idx, **O.slab_shape("D", "share"))
-    dx = formats.to_device(x)
-    streams = [torch.cuda.Stream() for _ in range(11)]
-    outs = [torch.zeros(n, dtype=torch.float64, device="cuda") for _ in streams]
-    torch.cuda.synchronize()
-    try:
-        for stream, dz in zip(streams, outs):
-            capi.spgpuSetStream(handle, C.c_void_p(stream.cuda_stream))
-            capi.hellspmv["D"](handle, _dp(dz), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]),
-                               _dp(h["rIdx"]), 14, n, _dp(dx), 0.0, 0)
-        torch.cuda.synchronize()
-        for k, dz in enumerate(outs):       # the default stream holds list 0, the first 7 streams given the others
-            want = with_list if k < 7 else without
-            assert dz.cpu().numpy().tobytes() == want.tobytes(), k
-    finally:
-        capi.spgpuSetStream(handle, None)
-        capi.spgpuDestroy(handle)
-
-
-@pytest.mark.parametrize("pattern,expect", [("banded", "strips"), ("near512", "xtile"), ("random", "gather")])
 @pytest.mark.parametrize("letter", ["D", "S"])
 def test_analysis_call_gives_the_form_at_once(gpu, pattern, expect, letter):
     """spgpuHellSpmvForm / spgpuEllSpmvForm: the answer AUTO settles on, synchronously, for a caller who holds it --

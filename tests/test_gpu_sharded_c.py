@@ -188,3 +188,17 @@ def test_a_rank_that_fails_its_set_up_takes_every_rank_out_together(gpu, mock_rc
                          capture_output=True, text=True, timeout=300, env=env)
     assert run.returncode == 0 and "ALL RANKS OK" in run.stdout and "did not finish" not in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]
     assert run.stdout.count("a peer's set-up failed") == 3
+
+
+def test_a_rank_with_a_wrong_partition_takes_every_rank_out_together(gpu, mock_rccl):
+    """A failure BEFORE the set-up proper -- here: one of three ranks is handed a row partition that does not fit its own block, the
+    check at the top of spgpuDhellspmmShardedCreate -- is agreed on like the set-up's own failures (sharded.h): every rank
+    returns an error, none waits in the set-up's first collective for a peer that has already left."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SPGPU_RCCL_LIBRARY=mock_rccl, SPGPU_TEST_BAD_PARTITION_RANK="2")
+    run = subprocess.run([sys.executable, os.path.join(here, "run_sharded_ranks.py"), "3", "window", "needed", "uneven"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode == 0 and "ALL RANKS OK" in run.stdout and "did not finish" not in run.stdout, run.stdout[-3000:] + run.stderr[-3000:]
+    assert run.stdout.count("a peer's set-up failed") == 3

@@ -45,7 +45,7 @@ torch.cuda.synchronize()
 capi.lib.spgpuDebugSetTrace(None)
 everything = trace[:8 * (groups + extra)].view(groups + extra, 8).cpu().numpy().astype(np.float64)
 ran = everything[:, 0] > 0
-spread = int(os.environ.get("SPGPU_PLAN_DEEP_SPREAD", "30"))
+spread = int(os.environ.get("SPGPU_PLAN_DEEP_SPREAD", "60"))
 deep_blocks = int(ran.sum()) - groups
 print(f"plan counts {capi.plan_counts(handle)}; workgroups that ran: {int(ran.sum())} = {groups} blocks of rows + {deep_blocks} of deep sub-groups (spread {spread})")
 grid = groups + deep_blocks
