@@ -1001,25 +1001,41 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
     alg = hell_algorithmic_bytes(nnz_local, rows_local, n_total, hacks, rhs=k)
     flops_total = 2.0 * nnz_local * k * world
 
-    if rank == 0:
-        # parity: a window of local rows against the oracle, bit for bit when the block is not split
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import numpy as np
-        import oracle_api as O
-        whole = synth.hell_uniform_on_device(rows_local, L, args.spmm_pattern, "D", 32, seed=11 + rank, device=dev,
-                                             n_cols=n_total, row_offset=first) if split else own
-        # X of every rank, regenerated here from the ranks' seeds (the check must not depend on the exchange under test)
-        x_everywhere = torch.cat([synth.device_vector(rows_local * k, "D", 21 + r, dev).view(rows_local, k) for r in range(world)])
+    # parity, on EVERY rank: a window of its own rows against the oracle (bit for bit when the block is not split), with the X of
+    # every rank regenerated from the ranks' seeds -- the first rows of a rank's block name columns of its neighbour's block, so a
+    # rank whose exchange delivered the wrong rows (or none) fails here.  The first real RCCL run of this code is the driver's
+    # scale run: the line says how many ranks were seen and how many of them checked out.
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_api as O
+    whole = synth.hell_uniform_on_device(rows_local, L, args.spmm_pattern, "D", 32, seed=11 + rank, device=dev,
+                                         n_cols=n_total, row_offset=first) if split else own
+    x_everywhere = torch.cat([synth.device_vector(rows_local * k, "D", 21 + r, dev).view(rows_local, k) for r in range(world)])
+    torch.cuda.synchronize()
+    sub = synth.hell_rows_to_host(whole, 0, 1024)
+    want = O.hell_spmm(sub, x_everywhere.cpu().numpy(), None, 1.0, 0.0)
+    del x_everywhere
+    got = z_local[:1024].cpu().numpy()
+    if split:
+        mine_ok = bool(np.max(np.abs(got - want) / (np.abs(want) + 1.0)) <= 1e-12)
+        parity = "within 1e-12 of oracle on 1024 rows (own+rest regroup the sums)" if mine_ok else "MISMATCH"
+    else:
+        mine_ok = got.tobytes() == want.tobytes()
+        parity = "bit-exact vs oracle on 1024 rows" if mine_ok else "MISMATCH"
+    ranks_seen, ranks_ok = 1, int(mine_ok)
+    if world > 1:
+        # one small all-gather of (rank, did my window check out) over the same backend as the run: who is there, who agrees
+        mine = torch.tensor([float(rank), 1.0 if mine_ok else 0.0], device=dev, dtype=torch.float64)
+        everyone_said = torch.zeros(2 * world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(everyone_said, mine)
         torch.cuda.synchronize()
-        sub = synth.hell_rows_to_host(whole, 0, 1024)
-        want = O.hell_spmm(sub, x_everywhere.cpu().numpy(), None, 1.0, 0.0)
-        del x_everywhere
-        got = z_local[:1024].cpu().numpy()
-        if split:
-            ok = np.max(np.abs(got - want) / (np.abs(want) + 1.0)) <= 1e-12
-            parity = "within 1e-12 of oracle on 1024 rows (own+rest regroup the sums)" if ok else "MISMATCH"
-        else:
-            parity = "bit-exact vs oracle on 1024 rows" if got.tobytes() == want.tobytes() else "MISMATCH"
+        said = everyone_said.cpu().numpy().reshape(world, 2)
+        ranks_seen = int(np.unique(said[:, 0]).size)
+        ranks_ok = int(said[:, 1].sum())
+        if ranks_ok != world:
+            parity += f"; {world - ranks_ok} of {world} ranks MISMATCH"
+
+    if rank == 0:
         out = dict(
             metric=(f"row-sharded HELL fp64 SpMM GFLOP/s (A x {k} rhs, weak scaling, {world} GPU" + ("s" if world > 1 else "") + ", "
                     + ("needed X rows by RCCL all_to_all" if needed_mode else "RCCL all-gather(X)") + " per step) + achieved HBM GB/s of the "
@@ -1045,6 +1061,9 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
                       allgather_GBps_per_rank=round((world - 1) * rows_local * k * 8 / t_gather * 1e-9, 1) if t_gather else None,
                       needed_rows_only_ms=round(t_needed * 1e3, 4) if both and t_needed else None,
                       needed_rows_received_per_rank=received, driver=driver,
+                      rccl_ranks_seen=ranks_seen, ranks_whose_window_matches_the_oracle=ranks_ok,
+                      exchange_bytes_per_rank=dict(allgather=(world - 1) * rows_local * k * 8,
+                                                   needed_rows=(received * k * 8 if received is not None else None)),
                       allgather_step_ms=round(t_step_allgather * 1e3, 4) if t_step_allgather else None,
                       allgather_step_gflops_total=round(flops_total / t_step_allgather * 1e-9, 1) if t_step_allgather else None),
             parity=parity, cpu_baseline=None)

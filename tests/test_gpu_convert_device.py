@@ -51,6 +51,17 @@ def _device_convert(gpu, n_rows, r, c, v, base, hack_size):
     return ell, hell
 
 
+def _hosts():
+    """Whom the device converters are compared with: the product's host converters (pinned to the reference's build in the CPU
+    suite, tests/test_oracle_vs_reference.py), the ORACLE's restatement of the reference's converters (ell.c:5-80, hell.c:4-104,
+    hdia.cpp:161-349, dia.c:5-104), and -- where oracle/_ref travelled with the tree -- the reference's own objects."""
+    from spgpu_amd import formats
+    sets = [("product host converters", formats), ("oracle", O.oracle_converters)]
+    if O.reference_available():
+        sets.append(("reference build", O.reference_converters()))
+    return sets
+
+
 def _same(dev, host, keys):
     for k in keys:
         a, b = dev[k], host[k]
@@ -68,11 +79,12 @@ def test_random_coo_matches_host_converters(gpu, letter):
     for trial in range(12):
         base, hs = int(rng.integers(0, 2)), int(rng.choice([32, 64, 96]))
         n_rows, n_cols, r, c, v = _random_coo(rng, letter, base)
-        ell_h = formats.coo_to_ell(n_rows, r, c, v, coo_base=base, ell_base=base)
-        hell_h = formats.ell_to_hell(ell_h, hs)
         ell_d, hell_d = _device_convert(gpu, n_rows, r, c, v, base, hs)
-        _same(ell_d, ell_h, ("max_row", "pitch", "row_lengths", "indices", "values"))
-        _same(hell_d, hell_h, ("height", "hack_offsets", "indices", "values"))
+        for _, host in _hosts():
+            ell_h = host.coo_to_ell(n_rows, r, c, v, coo_base=base, ell_base=base)
+            hell_h = host.ell_to_hell(ell_h, hs)
+            _same(ell_d, ell_h, ("max_row", "pitch", "row_lengths", "indices", "values"))
+            _same(hell_d, hell_h, ("height", "hack_offsets", "indices", "values"))
 
 
 def test_large_shuffled_power_law(gpu):
@@ -165,10 +177,11 @@ def test_device_coo_to_hdia_matches_host(gpu, letter):
         diagonals = np.unique(rng.integers(-n_rows + 1, n_cols, size=int(rng.integers(1, 12))))
         r, c, v = _diagonal_coo(rng, letter, base, n_rows, n_cols, diagonals, float(rng.choice([1.0, 0.6, 0.05])),
                                 int(rng.integers(0, 50)))
-        host = formats.coo_to_hdia(n_rows, n_cols, r, c, v, hs, coo_base=base)
         st, dev = _device_hdia(gpu, n_rows, n_cols, r, c, v, base, hs)
         assert st == capi.SPGPU_SUCCESS
-        _same(dev, host, ("height", "hack_offsets", "offsets", "values"))
+        for _, converters in _hosts():
+            host = converters.coo_to_hdia(n_rows, n_cols, r, c, v, hs, coo_base=base)
+            _same(dev, host, ("height", "hack_offsets", "offsets", "values"))
 
 
 def test_device_coo_to_hdia_scattered_and_empty(gpu):
@@ -195,10 +208,11 @@ def test_device_hdia_laplacian(gpu):
     import torch
     from spgpu_amd import capi, formats, synth
     n, _, r, c, v = synth.laplacian_3d_7pt(48)
-    host = formats.coo_to_hdia(n, n, r, c, v, 32)
     st, dev = _device_hdia(gpu, n, n, r, c, v, 0, 32)
     assert st == capi.SPGPU_SUCCESS
-    _same(dev, host, ("height", "hack_offsets", "offsets", "values"))
+    for _, converters in _hosts():
+        host = converters.coo_to_hdia(n, n, r, c, v, 32)
+        _same(dev, host, ("height", "hack_offsets", "offsets", "values"))
 
 
 # ---- COO -> DIA -------------------------------------------------------------------------------------------------
@@ -230,8 +244,11 @@ def test_device_coo_to_dia_matches_host(gpu, letter):
         assert capi.spgpuCooToDiaDevice(gpu, _p(values), _p(offsets), pitch, count.value, n_rows, n_cols, nnz, _p(dr), _p(dc), _p(dv),
                                         base, capi.TYPE_CODE[letter], _p(work), _p(scratch)) == capi.SPGPU_SUCCESS
         torch.cuda.synchronize()
-        assert offsets.cpu().numpy()[:count.value].tobytes() == host["offsets"].tobytes()
-        assert values.cpu().numpy()[:pitch * count.value].tobytes() == host["values"].tobytes()
+        for _, converters in _hosts():
+            host = converters.coo_to_dia(n_rows, n_cols, r, c, v, coo_base=base)
+            assert count.value == host["diags"]
+            assert offsets.cpu().numpy()[:count.value].tobytes() == host["offsets"].tobytes()
+            assert values.cpu().numpy()[:pitch * count.value].tobytes() == host["values"].tobytes()
     # an entry outside the matrix is reported
     bad = formats.to_device(np.array([0, 7], dtype=np.int32))
     work = torch.empty(capi.spgpuCooDiaWorkBytes(5, 5), dtype=torch.uint8, device="cuda:0")

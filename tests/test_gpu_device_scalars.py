@@ -5,7 +5,10 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import oracle_api as O
+
 pytestmark = pytest.mark.gpu
+EPS = {"S": 2.0 ** -24, "D": 2.0 ** -53}
 
 
 def _p(t):
@@ -25,6 +28,9 @@ def test_dot_device_equals_dot(gpu, letter, n, offset):
     want = capi.dot[letter](gpu, n, _p(a), _p(b))          # synchronises the handle's stream
     got = out.cpu().numpy()[0]
     assert np.asarray(got).tobytes() == np.asarray(want, dtype=got.dtype).tobytes()
+    # and against the ORACLE (ddot.cu:37-150 restated, ascending order): another order of additions, so within the rounding bound
+    ah, bh = a.cpu().numpy(), b.cpu().numpy()
+    assert abs(float(got) - float(O.dot(letter, ah, bh))) <= 2 * n * EPS[letter] * float(np.sum(np.abs(ah.astype(np.float64) * bh)))
     capi.dot_device[letter](gpu, _p(out), 0, _p(a), _p(b))  # empty vectors: 0
     torch.cuda.synchronize()
     assert out.cpu().numpy()[0] == 0
@@ -41,6 +47,8 @@ def test_nrm2_device_equals_nrm2(gpu, letter, n, offset):
     want = capi.nrm2[letter](gpu, n, _p(a))
     got = out.cpu().numpy()[0]
     assert np.asarray(got).tobytes() == np.asarray(want, dtype=got.dtype).tobytes()
+    oracle = float(O.nrm2(letter, a.cpu().numpy()))        # dnrm2.cu:52-53,146 restated
+    assert abs(float(got) - oracle) <= 2 * n * EPS[letter] * oracle
     capi.nrm2_device[letter](gpu, _p(out), 0, _p(a))
     torch.cuda.synchronize()
     assert out.cpu().numpy()[0] == 0
@@ -67,6 +75,8 @@ def test_axpby_and_div_device_equal_host_scalar_calls(gpu, letter):
     capi.axpby[letter](gpu, _p(z_host), n, capi.scalar(letter, beta), _p(y), capi.scalar(letter, alpha), _p(x))
     torch.cuda.synchronize()
     assert torch.equal(z_dev, z_host)
+    # and the oracle's axpby (daxpby.cu:31-45 restated) with the same coefficients: bit for bit
+    assert z_dev.cpu().numpy().tobytes() == O.axpby(letter, n, beta, y.cpu().numpy(), alpha, x.cpu().numpy()).tobytes()
     # *beta == 0 and beta == NULL: y is not read (NaNs in it do not reach z), as with spgpu?axpby(beta = 0)
     y_nan = torch.full_like(y, float("nan"))
     for beta_ptr in (scal[4:], None):
