@@ -174,7 +174,12 @@ static void startPlan(spgpuHandle_t handle, SpgpuSpmvPlan* plan, hipStream_t str
     const int blocks = (int)((subs + plan->subs - 1) / plan->subs);
     const size_t blockBytes = roundUp16((size_t)blocks * sizeof(SpgpuPlanBlock)), countBytes = roundUp16((size_t)blocks * sizeof(int));
     void* device = nullptr;
-    if (hipMalloc(&device, blockBytes + countBytes + (size_t)subs * sizeof(int)) != hipSuccess) {
+    int previous = 0;
+    (void)hipGetDevice(&previous); /* the plan lives where the handle's streams run, whatever device the caller has current */
+    (void)hipSetDevice(handle->device);
+    const hipError_t allocated = hipMalloc(&device, blockBytes + countBytes + (size_t)subs * sizeof(int));
+    (void)hipSetDevice(previous);
+    if (allocated != hipSuccess) {
         (void)hipGetLastError();
         plan->state = SPGPU_PLAN_EMPTY;
         return;
