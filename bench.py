@@ -52,7 +52,7 @@ def parse():
                         "one is measured in the same process and reported under `variants`")
     p.add_argument("--driver", default="c", choices=["c", "torch"],
                    help="spmm: who issues a step -- libspgpu.so's sharded driver (RCCL through dlopen), or torch.distributed")
-    p.add_argument("--placements", type=int, default=3,
+    p.add_argument("--placements", type=int, default=5,
                    help="north_star target: how many placements of the matrix' arrays (allocations of their own, one hipMalloc each) are timed")
     p.add_argument("--no-split", action="store_true",
                    help="spmm: do not cut the local block by column ownership (no compute/all-gather overlap)")
