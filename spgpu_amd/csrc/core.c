@@ -55,7 +55,7 @@ static void deepListFor(SpgpuPrivateHandle* h, hipStream_t stream)
         for (int i = 0; i < h->deepStreams; ++i) {
             if (h->deepStream[i] == h->pub.defaultStream)
                 continue; /* the default stream always comes back (spgpuSetStream(h, 0)) */
-            if (h->deepUsed[i] && hipEventQuery(h->deepIdle[i]) != hipSuccess)
+            if (h->deepUsed[i] && !spgpuEventDone(h->deepIdle[i]))
                 continue;
             if (pick < 0 || h->deepClock[i] < h->deepClock[pick])
                 pick = i;
@@ -380,7 +380,7 @@ SpgpuSpmvPlan* spgpuPlanRecord(spgpuHandle_t pHandle, const SpgpuSpmvPlan* key)
             return p;
         }
         /* a record whose analysis is still in flight keeps its buffer and its pinned words until it has landed */
-        if (p->state == SPGPU_PLAN_BUILDING && hipEventQuery(p->built) != hipSuccess)
+        if (p->state == SPGPU_PLAN_BUILDING && !spgpuEventDone(p->built))
             continue;
         if (!oldest || p->rows == 0 || (oldest->rows != 0 && p->clock < oldest->clock))
             oldest = p;

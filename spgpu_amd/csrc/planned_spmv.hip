@@ -300,7 +300,7 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
         spgpuPlanLock(handle);
         SpgpuSpmvPlan* plan = spgpuPlanRecord(handle, &key);
         if (plan) {
-            if (plan->state == SPGPU_PLAN_BUILDING && hipEventQuery(plan->built) == hipSuccess) {
+            if (plan->state == SPGPU_PLAN_BUILDING && spgpuEventDone(plan->built)) {
                 plan->deep = ((volatile int*)plan->pinned)[0];
                 plan->state = SPGPU_PLAN_READY;
             }

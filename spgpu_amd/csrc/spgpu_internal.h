@@ -156,6 +156,18 @@ SpgpuSpmvPlan* spgpuPlanRecord(spgpuHandle_t h, const SpgpuSpmvPlan* key);
  * after a device-wide wait.  State EMPTY afterwards. */
 void spgpuPlanRetire(spgpuHandle_t h, SpgpuSpmvPlan* plan);
 
+/* Has everything recorded into `event` finished?  hipEventQuery says hipErrorNotReady for "not yet" -- an answer, not a
+ * failure -- but the runtime also leaves it behind as the thread's last error, where a caller in the reference's style
+ * (hellPerf.cpp:385-390: cudaGetLastError after the launches) would find it and report a failed SpMV.  It is taken back here;
+ * any other error the caller has not looked at yet stays where it is. */
+static inline int spgpuEventDone(hipEvent_t event)
+{
+    const hipError_t said = hipEventQuery(event);
+    if (said == hipErrorNotReady && hipPeekAtLastError() == hipErrorNotReady)
+        (void)hipGetLastError();
+    return said == hipSuccess;
+}
+
 /* With -DSPGPU_DEBUG every launch is followed by a synchronising error check
  * that prints and exits, as the reference does under -DDEBUG
  * (kernels/cudadebug.h:12-25).  Otherwise launch errors surface through the

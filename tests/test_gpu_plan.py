@@ -257,3 +257,22 @@ def test_streams_come_and_go_lists_change_hands(gpu):
         capi.spgpuSetStream(gpu, None)
     assert capi.spgpuDeepListFallbacks(gpu) == fallbacks0
     assert capi.spgpuDeepListsRecycled(gpu) > recycled0
+
+
+def test_no_error_left_behind_for_the_caller(gpu):
+    """A caller in the reference's style asks cudaGetLastError after its launches (hellPerf.cpp:385-390).  While a matrix' analysis
+    is still in flight the library polls its event; "not ready" is an answer, not an error, and must not be what the caller finds."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    hip = C.CDLL("libamdhip64.so")
+    n = 200 * 2048
+    h = _matrix(gpu, n, "D", 2048, 60, True, seed=29)
+    dx = formats.to_device(synth.values_for("D", 95, n))
+    dz = torch.zeros(n, dtype=dx.dtype, device="cuda")
+    torch.cuda.synchronize()
+    assert hip.hipGetLastError() == 0
+    for _ in range(6):                       # back to back: the later calls find the analysis (queued behind the first) not finished yet
+        _call(gpu, "D", h, n, dz, None, dx, 1.0, 0.0)
+    assert hip.hipGetLastError() == 0
+    torch.cuda.synchronize()
+    assert hip.hipGetLastError() == 0
