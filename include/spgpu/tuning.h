@@ -73,6 +73,18 @@ int spgpuDeepListsRecycled(spgpuHandle_t handle);
  * spgpuSpmvPlanCounts: launches that ran with a plan, analyses started, plans found stale (any pointer may be NULL).
  */
 void spgpuSpmvPlanCounts(spgpuHandle_t handle, int* uses, int* builds, int* stales);
+/*
+ * For a caller who does not want its first calls to differ from its later ones (a benchmark without warm-up calls, a graph
+ * captured right after the matrix was built): everything a first SpMV on these arrays would leave to later calls -- the
+ * ordered matrix' workgroup shape, its plan -- is worked out now, on the handle's current stream, and WAITED for.  Arguments as
+ * in the SpMV call that will follow (cM is only looked at for its alignment).  SPGPU_SUCCESS: the next spgpu?hellspmv /
+ * spgpu?ellspmv on these arrays (same rIdx, baseIndex, form) runs from the plan; SPGPU_UNSUPPORTED: calls of this kind have no
+ * plan (no rIdx, SPGPU_PLAN=0, a layout that takes the narrow kernels) -- nothing to prepare, nothing wrong.
+ */
+int spgpuHellSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,
+                         const int* rIdx, int rows, int baseIndex);
+int spgpuEllSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int cMPitch, int rPPitch, const int* rS, const int* rIdx,
+                        int maxNnzPerRow, int rows, int baseIndex);
 
 void spgpuTuningReload(void);
 /* 1 if the library was built with -DSPGPU_TUNING_VARIANTS: the non-default kernel shapes (SPGPU_SPMV_VARIANT, SPGPU_X_TILE_SHAPE,

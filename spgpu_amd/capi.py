@@ -259,6 +259,8 @@ spgpuDeepListOverflows = _decl("spgpuDeepListOverflows", i32, [Handle])
 spgpuDeepListFallbacks = _decl("spgpuDeepListFallbacks", i32, [Handle])
 spgpuDeepListsRecycled = _decl("spgpuDeepListsRecycled", i32, [Handle])
 spgpuSpmvPlanCounts = _decl("spgpuSpmvPlanCounts", None, [Handle, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)])
+spgpuHellSpmvPrepare = _decl("spgpuHellSpmvPrepare", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, ptr, i32, i32])
+spgpuEllSpmvPrepare = _decl("spgpuEllSpmvPrepare", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, ptr, i32, i32, i32])
 
 
 def plan_counts(handle):

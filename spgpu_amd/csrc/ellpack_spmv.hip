@@ -1127,8 +1127,13 @@ static void launchFormProbe(hipStream_t stream, const SlabArgs<T>& a, bool wideO
 }
 
 template <typename T, bool IS_HELL>
-static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
+static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* prepared = nullptr)
 {
+    /* prepared != NULL (spgpu?SpmvPrepare, include/spgpu/tuning.h): nothing is multiplied -- the choices a first SpMV would leave
+     * to later calls are made now and waited for: the ordered matrix' workgroup shape (the probe) and its plan.
+     * *prepared: 1 = the next SpMV on these arrays runs from a plan; 0 = this kind of call has none. */
+    if (prepared)
+        *prepared = 0;
     if (in.rows <= 0)
         return;
     SlabArgs<T> a = in;
@@ -1182,6 +1187,8 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
     if (form == SPGPU_SPMV_FORM_SWEEP) {
         /* the caller's choice for scattered columns that ascend inside a row; needs 16-byte slab accesses and no row order */
         if (wideOk && !a.rIdx && tune->spmvVariant < 1) {
+            if (prepared)
+                return;
             a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
             a.feedback = nullptr;
             spgpuNoteSpmvForm(handle, SPGPU_SPMV_FORM_SWEEP);
@@ -1221,6 +1228,8 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         }
     }
 #ifdef SPGPU_TUNING_VARIANTS /* two stateless one-launch kernels of round 3, kept for A/B runs (another order of additions: chunks of 48 columns) */
+    if (prepared && (tune->ragged == 2 || tune->ragged == 3))
+        return;
     if (a.rIdx != nullptr && wideOk && (variant == 21 || variant == 22) && tune->ragged == 3) {
         /* rows ordered by length: one resident workgroup per CU, the next block prepared beside the stream (pipe_spmv.hip.h) */
         a.wideIO = 0;
@@ -1258,10 +1267,12 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
              * read without synchronisation: a first call runs the 1 024-row shape, which is never far off) */
             int calls = 0, tag = 0;
             int* seen = spgpuFormFeedback(handle, a.rP, a.rows, &calls, &tag);
-            const int said = spgpuFeedbackSaid(((volatile int*)seen)[3], tag);
+            int said = spgpuFeedbackSaid(((volatile int*)seen)[3], tag);
             if (said == 0 || calls % 64 == 0)
                 hipLaunchKernelGGL((orderedProbeKernel<IS_HELL>), dim3(1), dim3(kWave), 0, stream, a.rP, a.rS, a.hackOffsets, a.rIdx, a.hackSize,
                                    a.idxStride, a.maxNnz, a.rows, a.baseIndex, seen + 3, tag);
+            if (prepared && said == 0 && hipStreamSynchronize(stream) == hipSuccess)
+                said = spgpuFeedbackSaid(((volatile int*)seen)[3], tag); /* the answer a second call would have found */
             shape = said == 4 || said == 6 ? 4 : 0; /* 6: the blocks are the windows of an aligned order */
         }
         /* a matrix seen before has a plan (planned_spmv.hip): one launch, the deep sub-groups in workgroups of their own, no
@@ -1272,7 +1283,12 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
         const bool tiledForm = form != SPGPU_SPMV_FORM_GATHER;
         if (noDeepList && !(shape == 4 || shape == 5))
             shape = 0;
-        if ((!tiledForm || shape == 0 || shape == 4 || shape == 5) && launchPlanned<T, IS_HELL>(handle, stream, a, shape, tiledForm, noDeepList))
+        if (prepared) {
+            if (!tiledForm || shape == 0 || shape == 4 || shape == 5)
+                *prepared = launchPlanned<T, IS_HELL>(handle, stream, a, shape, tiledForm, false, true) ? 1 : 0;
+            return;
+        }
+        if ((!tiledForm || shape == 0 || shape == 4 || shape == 5) && launchPlanned<T, IS_HELL>(handle, stream, a, shape, tiledForm, noDeepList, false))
             return;
         const bool deepKernels = launchRagged<T, WIDE, IS_HELL, true>(stream, a, shape, form != SPGPU_SPMV_FORM_GATHER);
         if (deepPossible && deepKernels)
@@ -1281,6 +1297,8 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in)
             (void)hipEventRecord(list.idle, stream); /* complete = the list has no user (core.c: a list may change hands) */
         return;
     }
+    if (prepared)
+        return; /* (the forms below learn what they need from their own launches) */
 #ifdef SPGPU_TUNING_VARIANTS
     if (deepSplit) {
         /* shapes in which a lane walks whole rows, for every type; the strip form does not apply to ordered rows */
@@ -1467,6 +1485,43 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
     spgpuDebugCheck(handle, "ellspmv");
 }
 
+/* spgpu?SpmvPrepare (include/spgpu/tuning.h): the dispatch of an SpMV on these arrays, with nothing multiplied */
+template <typename T, bool IS_HELL>
+static int prepareSpmv(spgpuHandle_t handle, const void* cM, const int* rP, int hackSize, const int* hackOffsets, long long valStride, long long idxStride,
+                       const int* rS, const int* rIdx, int maxNnz, int rows, int baseIndex)
+{
+    SlabArgs<T> a{};
+    a.cM = static_cast<const T*>(cM);
+    a.rP = rP;
+    a.rS = rS;
+    a.rIdx = rIdx;
+    a.hackOffsets = hackOffsets;
+    a.rows = rows;
+    a.baseIndex = baseIndex;
+    a.hackSize = hackSize;
+    a.maxNnz = maxNnz;
+    a.valStride = valStride;
+    a.idxStride = idxStride;
+    int prepared = 0;
+    launchSlabFamily<T, IS_HELL>(handle, a, &prepared);
+    return prepared ? SPGPU_SUCCESS : SPGPU_UNSUPPORTED;
+}
+
+template <bool IS_HELL>
+static int prepareSpmvOfType(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, long long valStride,
+                             long long idxStride, const int* rS, const int* rIdx, int maxNnz, int rows, int baseIndex)
+{
+    if (!handle || !rP || !cM || rows < 0)
+        return SPGPU_UNSPECIFIED;
+    switch (type) {
+    case SPGPU_TYPE_FLOAT: return prepareSpmv<float, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex);
+    case SPGPU_TYPE_DOUBLE: return prepareSpmv<double, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex);
+    case SPGPU_TYPE_COMPLEX_FLOAT: return prepareSpmv<cfloat, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex);
+    case SPGPU_TYPE_COMPLEX_DOUBLE: return prepareSpmv<cdouble, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex);
+    default: return SPGPU_UNSPECIFIED;
+    }
+}
+
 /* ---- ELL coefficient update (include/spgpu/ell.h; reference ell_csput_base.cuh:33-75) ---- */
 template <typename T>
 __global__ __launch_bounds__(kBlockThreads) void ellCsputKernel(T* cM, const int* rP, long long cMPitch, long long rPPitch,
@@ -1576,6 +1631,20 @@ int spgpuHellSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int
                       int baseIndex)
 {
     return analyseFormOfType<true>(handle, type, rP, hackSize, hackOffsets, hackSize, rS, 0, rows, baseIndex);
+}
+
+int spgpuHellSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,
+                         const int* rIdx, int rows, int baseIndex)
+{
+    if (!hackOffsets || !rS || hackSize <= 0)
+        return SPGPU_UNSPECIFIED;
+    return spgpu::prepareSpmvOfType<true>(handle, type, cM, rP, hackSize, hackOffsets, hackSize, hackSize, rS, rIdx, 0, rows, baseIndex);
+}
+
+int spgpuEllSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int cMPitch, int rPPitch, const int* rS, const int* rIdx,
+                        int maxNnzPerRow, int rows, int baseIndex)
+{
+    return spgpu::prepareSpmvOfType<false>(handle, type, cM, rP, 0, nullptr, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, baseIndex);
 }
 
 int spgpuEllSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int rPPitch, const int* rS, int maxNnzPerRow, int rows,

@@ -224,9 +224,10 @@ static void startPlan(spgpuHandle_t handle, SpgpuSpmvPlan* plan, hipStream_t str
  * mustLaunch: the caller has no deep list for this stream -- without a ready plan the same kernel runs with NO plan: nothing
  * is listed, every sub-group deeper than the cap is worked off by its own block behind its stream, no x tile.  Stateless,
  * slower, the same bits.
+ * prepareOnly (spgpu?SpmvPrepare): nothing is launched but the analysis, and that is waited for: true = the plan is ready.
  */
 template <typename T, bool IS_HELL>
-bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled, bool mustLaunch)
+bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled, bool mustLaunch, bool prepareOnly)
 {
     constexpr int RPL = 16 / (int)sizeof(T);
     constexpr int UNROLL = SPGPU_RAGGED_UNROLL(RPL);
@@ -314,8 +315,14 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
                 if (giveUp)
                     plan->state = SPGPU_PLAN_GIVEN_UP;
             }
-            if (plan->state == SPGPU_PLAN_EMPTY) {
+            if (plan->state == SPGPU_PLAN_EMPTY)
                 startPlan<IS_HELL>(handle, plan, stream);
+            if (prepareOnly) {
+                if (plan->state == SPGPU_PLAN_BUILDING && hipEventSynchronize(plan->built) == hipSuccess) {
+                    plan->deep = ((volatile int*)plan->pinned)[0];
+                    plan->state = SPGPU_PLAN_READY;
+                }
+                launched = plan->state == SPGPU_PLAN_READY;
             } else if (plan->state == SPGPU_PLAN_READY) {
                 const size_t blockBytes = roundUp16((size_t)plan->blocks * sizeof(SpgpuPlanBlock)), countBytes = roundUp16((size_t)plan->blocks * sizeof(int));
                 a.planBlocks = static_cast<const SpgpuPlanBlock*>(plan->device);
@@ -331,21 +338,21 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
         }
         spgpuPlanUnlock(handle);
     }
-    if (!launched && mustLaunch) {
+    if (!launched && mustLaunch && !prepareOnly) {
         launch();
         launched = true;
     }
     return launched;
 }
 
-template bool launchPlanned<float, true>(spgpuHandle_t, hipStream_t, const SlabArgs<float>&, int, bool, bool);
-template bool launchPlanned<float, false>(spgpuHandle_t, hipStream_t, const SlabArgs<float>&, int, bool, bool);
-template bool launchPlanned<double, true>(spgpuHandle_t, hipStream_t, const SlabArgs<double>&, int, bool, bool);
-template bool launchPlanned<double, false>(spgpuHandle_t, hipStream_t, const SlabArgs<double>&, int, bool, bool);
-template bool launchPlanned<cfloat, true>(spgpuHandle_t, hipStream_t, const SlabArgs<cfloat>&, int, bool, bool);
-template bool launchPlanned<cfloat, false>(spgpuHandle_t, hipStream_t, const SlabArgs<cfloat>&, int, bool, bool);
-template bool launchPlanned<cdouble, true>(spgpuHandle_t, hipStream_t, const SlabArgs<cdouble>&, int, bool, bool);
-template bool launchPlanned<cdouble, false>(spgpuHandle_t, hipStream_t, const SlabArgs<cdouble>&, int, bool, bool);
+template bool launchPlanned<float, true>(spgpuHandle_t, hipStream_t, const SlabArgs<float>&, int, bool, bool, bool);
+template bool launchPlanned<float, false>(spgpuHandle_t, hipStream_t, const SlabArgs<float>&, int, bool, bool, bool);
+template bool launchPlanned<double, true>(spgpuHandle_t, hipStream_t, const SlabArgs<double>&, int, bool, bool, bool);
+template bool launchPlanned<double, false>(spgpuHandle_t, hipStream_t, const SlabArgs<double>&, int, bool, bool, bool);
+template bool launchPlanned<cfloat, true>(spgpuHandle_t, hipStream_t, const SlabArgs<cfloat>&, int, bool, bool, bool);
+template bool launchPlanned<cfloat, false>(spgpuHandle_t, hipStream_t, const SlabArgs<cfloat>&, int, bool, bool, bool);
+template bool launchPlanned<cdouble, true>(spgpuHandle_t, hipStream_t, const SlabArgs<cdouble>&, int, bool, bool, bool);
+template bool launchPlanned<cdouble, false>(spgpuHandle_t, hipStream_t, const SlabArgs<cdouble>&, int, bool, bool, bool);
 
 } // namespace spgpu
 

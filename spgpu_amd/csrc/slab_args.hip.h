@@ -109,7 +109,7 @@ struct ColumnProbe {
 
 
 /* planned_spmv.hip: the ordered SpMV with the matrix's plan, if it has one that is ready (true: launched, nothing follows) */
-template <typename T, bool IS_HELL> bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled, bool mustLaunch);
+template <typename T, bool IS_HELL> bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled, bool mustLaunch, bool prepareOnly);
 
 constexpr int kDeepChunk = 64; /* columns per deep item; measured: items of 32 / 64 / 128 columns and stages of 16 / 32 within 8 % -- the kernel is bound by the lines its gathers pull */
 

@@ -276,3 +276,26 @@ def test_no_error_left_behind_for_the_caller(gpu):
     assert hip.hipGetLastError() == 0
     torch.cuda.synchronize()
     assert hip.hipGetLastError() == 0
+
+
+@pytest.mark.parametrize("letter", ["D", "S", "Z"])
+def test_prepare_makes_the_first_call_a_planned_one(gpu, letter):
+    """spgpuHellSpmvPrepare (include/spgpu/tuning.h): probe and analysis now, waited for -- the very first SpMV on the arrays runs
+    from the plan (and gives the oracle's bits); without rIdx there is nothing to prepare (SPGPU_UNSUPPORTED, not an error)."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 7 * 2048 + 31
+    h = _matrix(gpu, n, letter, 2048, 60, True, seed=31, longest=700, near=400)
+    x = synth.values_for(letter, 97, n)
+    dx = formats.to_device(x)
+    want = O.spmv_tail(_host(h, letter, n), x, None, 1.0, 0.0, r_idx=h["rIdx"].cpu().numpy(), **O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP))
+    torch.cuda.synchronize()
+    code = capi.TYPE_CODE[letter]
+    assert capi.spgpuHellSpmvPrepare(gpu, code, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), _dp(h["rIdx"]), n, 0) == capi.SPGPU_SUCCESS
+    uses = capi.plan_counts(gpu)[0]
+    dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+    _call(gpu, letter, h, n, dz, None, dx, 1.0, 0.0)
+    torch.cuda.synchronize()
+    assert capi.plan_counts(gpu)[0] == uses + 1
+    assert dz.cpu().numpy().tobytes() == want.tobytes()
+    assert capi.spgpuHellSpmvPrepare(gpu, code, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), None, n, 0) == capi.SPGPU_UNSUPPORTED
