@@ -299,3 +299,26 @@ def test_prepare_makes_the_first_call_a_planned_one(gpu, letter):
     assert capi.plan_counts(gpu)[0] == uses + 1
     assert dz.cpu().numpy().tobytes() == want.tobytes()
     assert capi.spgpuHellSpmvPrepare(gpu, code, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), None, n, 0) == capi.SPGPU_UNSUPPORTED
+
+
+def test_prepare_ell_with_a_row_order(gpu):
+    """The ELL flavour: any rIdx selects the ordered path; prepared, the first spgpuDellspmv runs from the plan, oracle bits."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 3000
+    lengths = np.minimum(np.random.default_rng(5).zipf(1.5, size=n), 300)
+    _, _, r, c, v = synth.random_rows_coo(n, n, lengths, seed=6, letter="D")
+    ell = formats.coo_to_ell(n, r, c, v)
+    perm = np.random.default_rng(7).permutation(n).astype(np.int32)
+    dev = formats.DeviceEll(ell, r_idx=perm)
+    x = synth.values_for("D", 99, n)
+    dx = formats.to_device(x)
+    torch.cuda.synchronize()
+    assert capi.spgpuEllSpmvPrepare(gpu, capi.TYPE_CODE["D"], _dp(dev.cM), _dp(dev.rP), dev.pitch, dev.pitch, _dp(dev.rS), _dp(dev.rIdx), dev.max_row,
+                                    n, 0) == capi.SPGPU_SUCCESS
+    uses = capi.plan_counts(gpu)[0]
+    dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+    dev.spmv(gpu, dz, None, 1.0, dx, 0.0)
+    torch.cuda.synchronize()
+    assert capi.plan_counts(gpu)[0] == uses + 1
+    assert dz.cpu().numpy().tobytes() == O.default_spmv(ell, x, None, 1.0, 0.0, r_idx=perm).tobytes()
