@@ -57,6 +57,7 @@ template <typename T> struct SpmmArgs {
     int count;      /* right-hand sides in this pass (<= KP*VEC) */
     int tileRows;   /* tiled kernel: X rows the LDS tile can hold */
     int directFill; /* strip kernel: every 16-byte piece of a tile row is 16 valid, aligned bytes of X (global_load_lds) */
+    int bandMode;   /* strip kernel: wavefronts whose rows form a band take the sliding-window loop (SPGPU_SPMM_VARIANT=11: never) */
     long long ldX, ldYZ;
 };
 
@@ -643,6 +644,28 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
     }
     const bool useTile = fitsSoFar && hi >= lo && (long long)hi - lo < a.tileRows; /* workgroup-uniform */
 
+    /* BAND wavefronts.  In a band or stencil matrix in natural order row r + 1 names the columns of row r shifted by one, and a
+     * row's entries ascend by one: over the 8 rows of a team and 8 slab columns only 15 different X rows occur, each used up to 8
+     * times.  A wavefront all of whose 64 rows have that shape through ALL their columns -- column of (row i, slab column k) =
+     * bandBase + k + i, every row exactly groupLongest <= 32 entries long; checked here against the indices of the head, one
+     * ballot -- takes a loop of its own below: a team keeps a sliding window of 8 X rows in registers and reads ONE new row per
+     * slab column from the tile instead of 8, needs no offsets from the loader lanes (only the coefficients go through LDS), and
+     * never looks at an index again (the head's 32 registers are dead in that loop: the window takes their place).  It is the
+     * SpMM counterpart of the SpMV's strip x loads.  Same products, added in the same order: ascending k. */
+    int bandBase = -1; /* relative to lo; wavefront-uniform */
+    if (a.bandMode && useTile && groupLongest > 0 && groupLongest <= kStageCols * HEAD && groupLongest % (kStageCols * TRIP) == 0) {
+        const int base = __builtin_amdgcn_readfirstlane(head[0].v[0] - a.baseIndex - lo);
+        bool off = false;
+#pragma unroll
+        for (int u = 0; u < HEAD; ++u) {
+            const int k = kStageCols * u + iCol;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                off |= k < groupLongest && (iLen[j] != groupLongest || head[u].v[j] - a.baseIndex - lo != base + k + 32 * iHalf + 4 * iQ + j);
+        }
+        bandBase = __ballot(off) == 0ull && groupRow0 + kWave <= a.rows ? base : -1;
+    }
+
     auto loadTrip = [&](int k0, Trip& t) {
 #pragma unroll
         for (int s = 0; s < TRIP; ++s) {
@@ -700,7 +723,91 @@ __global__ __launch_bounds__(kSpmmThreads) __attribute__((amdgpu_waves_per_eu(3,
         for (int e = 0; e < VEC; ++e)
             sum[i][e] = zeroOf<T>();
 
-    if (!useTile) {
+    if (bandBase >= 0) {
+        static_assert(kStageCols * TRIP == KP, "the window's names come round once per trip");
+        const int team = lane / KP;
+        const int rhs0 = (lane % KP) * VEC;
+        const int rhsSafe = rhs0 < a.count ? rhs0 : 0;
+        const unsigned char* const myTile = reinterpret_cast<const unsigned char*>(tile) + rhsSafe * sizeof(T);
+        auto tileRow = [&](int r) { return loadPack<false, T, VEC>(reinterpret_cast<const T*>(myTile + tileOffset(r))); };
+        /* X rows first + C .. first + C + 7 of slab column C (counted from 0), by rotating name: row first + C + i sits in
+         * window[(C + i) % 8]; a trip of 8 columns brings the names round once, so the window carries on from trip to trip */
+        int newest = bandBase + KP * team + KP - 1; /* the row that enters with the next slab column */
+        Pack<T, VEC> window[KP];
+#pragma unroll
+        for (int i = 0; i + 1 < KP; ++i)
+            window[i] = tileRow(newest - (KP - 1) + i);
+        Pack<T, CR> coefNow[TRIP * COEF_LOADS], coefNext[TRIP * COEF_LOADS];
+#pragma unroll
+        for (int q = 0; q < TRIP * COEF_LOADS; ++q) { /* requested with the tile fill, above */
+            coefNow[q] = cur.coef[q];
+            coefNext[q] = next.coef[q];
+        }
+        /* every row of the wavefront is groupLongest long: the bounds of the coefficient loads are wavefront-uniform, and a
+         * lane's loads of one trip differ from the previous trip's by a uniform stride */
+        const T* coefAt = cBase + ((long long)(2 * STEP) + cCol) * hs; /* this lane's first load of the trip after next */
+        const long long tripStride = (long long)STEP * hs, loadStride = (long long)COLS_PER_COEF_LOAD * hs, stageStride = (long long)kStageCols * hs;
+        const T* const stageCoefRead = &stage->coef[0][KP * team];
+        T* const stageCoefWrite = &stage->coef[cCol][32 * cHalf + CR * cQ];
+#pragma clang loop unroll(disable)
+        for (int k0 = 0; k0 < groupLongest; k0 += STEP) {
+            /* the trip after next: coefficients only, requested BEFORE this trip is consumed (a third set of registers: this
+             * loop has them to spare), so that all of a 32-column row's matrix bytes are on their way within the first trip */
+            Pack<T, CR> coefAfter[TRIP * COEF_LOADS];
+            if (k0 + 2 * STEP < groupLongest) { /* wavefront-uniform */
+#pragma unroll
+                for (int s = 0; s < TRIP; ++s)
+#pragma unroll
+                    for (int j = 0; j < COEF_LOADS; ++j)
+                        coefAfter[s * COEF_LOADS + j] = loadPack<true, T, CR>(coefAt + s * stageStride + j * loadStride);
+            }
+            coefAt += tripStride;
+#pragma unroll
+            for (int s = 0; s < TRIP; ++s) {
+                waveSync();
+#pragma unroll
+                for (int j = 0; j < COEF_LOADS; ++j)
+                    storePack<T, CR>(stageCoefWrite + COLS_PER_COEF_LOAD * j * kWave, coefNow[s * COEF_LOADS + j]);
+                waveSync();
+#pragma unroll
+                for (int c = 0; c < kStageCols; ++c) {
+                    const int C = kStageCols * s + c; /* compile-time after unrolling */
+                    window[(C + KP - 1) % KP] = tileRow(newest);
+                    newest += 1;
+#pragma unroll
+                    for (int i0 = 0; i0 < KP; i0 += 4) {
+                        T coef[4];
+#pragma unroll
+                        for (int j0 = 0; j0 < 4; j0 += CR) {
+                            const Pack<T, CR> part = loadPack<false, T, CR>(stageCoefRead + c * kWave + i0 + j0);
+#pragma unroll
+                            for (int j = 0; j < CR; ++j)
+                                coef[j0 + j] = part.v[j];
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e)
+                                sum[i0 + i][e] = mulAdd(coef[i], window[(C + i0 + i) % KP].v[e], sum[i0 + i][e]);
+                        /* The multiply-adds have no place of their own in the order of the block (nothing but the next
+                         * iteration needs the sums): left alone, the compiler gathers all 128 of a trip behind all 40 LDS
+                         * reads and spills what the reads delivered.  The empty statements tie each chunk's sums down here. */
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e)
+                                asm volatile("" : "+v"(sum[i0 + i][e]));
+                        __builtin_amdgcn_sched_barrier(0); /* keep the reads of later chunks from being hoisted: registers */
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TRIP * COEF_LOADS; ++q) {
+                coefNow[q] = coefNext[q];
+                coefNext[q] = coefAfter[q];
+            }
+        }
+    } else if (!useTile) {
         /* window too wide for the tile: one row per lane, X through L1/L2 (the plain kernel's loop) */
         const long long myRow = groupRow0 + lane;
         int myLen = 0;
@@ -816,6 +923,7 @@ template <typename T, int TRIP, int VEC = 2> static void launchSpmmStrips(hipStr
     /* whole tile rows of valid bytes: all KP * VEC right-hand sides present, rows of X 16-byte aligned */
     a.directFill = a.count == 8 * VEC && (8 * VEC * sizeof(T)) % 16 == 0 && (uintptr_t)a.X % 16 == 0 &&
                    (a.ldX * (long long)sizeof(T)) % 16 == 0 && spgpuTuning()->spmmVariant != 10;
+    a.bandMode = spgpuTuning()->spmmVariant != 11;
     const size_t lds = kStripTileBytes + (kSpmmThreads / kWave) * sizeof(SpmmStage<T>);
     hipLaunchKernelGGL((hellSpmmStripKernel<T, TRIP, VEC>), dim3(blocks), dim3(kSpmmThreads), lds, stream, a);
 }
@@ -864,6 +972,7 @@ static void hellSpmm(spgpuHandle_t handle, T* Z, const T* Y, T alpha, const T* c
         a.ldYZ = ldYZ;
         a.tileRows = 0;
         a.directFill = 0;
+        a.bandMode = 0;
         const bool pairs = pairsOk && a.count % 2 == 0;
         /* 16-byte loads of whole 32-row half columns */
         const bool strips = pairs && hackSize % 32 == 0 && (uintptr_t)cM % 16 == 0 && (uintptr_t)rP % 16 == 0;
