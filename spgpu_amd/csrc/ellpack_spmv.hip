@@ -1205,6 +1205,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
     a.deepCap = tune->deepCap > 0 ? tune->deepCap : 256;
     a.deepKeep = tune->deepKeep >= 0 && tune->deepKeep < a.deepCap ? tune->deepKeep : a.deepCap;
     a.xcdRun = tune->xcdOrder;
+    a.stageLate = tune->stageLate != 0;
     a.deepChunk = kDeepChunk;
     a.deepHeader = nullptr;
     a.deepEntries = nullptr;

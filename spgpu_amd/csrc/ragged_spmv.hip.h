@@ -285,23 +285,29 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     }
     __syncthreads();
     int zBase = 0;
-    if constexpr (ZSTAGE) {
-        static_assert(WAVES <= 16, "one DPP row holds the wavefronts' words");
-        zBase = waveReduce(waveLowestDest[lane < WAVES ? lane : 0], MinOf{}); /* one LDS read per lane, the minimum by DPP */
+    /* Where each row's result will wait (ZSTAGE).  Nothing needs this before the end of a wavefront's first item, and the
+     * tile's barrier lies between: it is done while the tile and the first stages are on their way (round 4: it used to stand
+     * here, 2.4 us of LDS traffic between the lengths' arrival and the first request of the stream). */
+    auto stageDestinations = [&]() {
+        if constexpr (ZSTAGE) {
+            static_assert(WAVES <= 16, "one DPP row holds the wavefronts' words");
+            zBase = waveReduce(waveLowestDest[lane < WAVES ? lane : 0], MinOf{}); /* one LDS read per lane, the minimum by DPP */
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const int i = threadIdx.x + j * BLOCK;
-            if (i < ROWS) {
-                const long long off = (long long)myDest[j] - zBase;
-                /* (rows of a deep sub-group are finished by the deep kernels: nothing of theirs is staged) */
-                const bool in = blockRow0 + i < a.rows && off >= 0 && off < ZW && stagedHere[j];
-                destOffset[i] = in ? (unsigned short)off : (unsigned short)0xFFFF;
-                if (in)
-                    atomicOr(&stagedMask[off >> 5], 1u << (off & 31));
+            for (int j = 0; j < RPT; ++j) {
+                const int i = threadIdx.x + j * BLOCK;
+                if (i < ROWS) {
+                    const long long off = (long long)myDest[j] - zBase;
+                    /* (rows of a deep sub-group are finished by the deep kernels: nothing of theirs is staged) */
+                    const bool in = blockRow0 + i < a.rows && off >= 0 && off < ZW && stagedHere[j];
+                    destOffset[i] = in ? (unsigned short)off : (unsigned short)0xFFFF;
+                    if (in)
+                        atomicOr(&stagedMask[off >> 5], 1u << (off & 31));
+                }
             }
         }
-        /* (read by the wavefronts at the end of their first sub-group at the earliest: the tile's barrier lies between) */
-    }
+    };
+    if (!XTILE || !a.stageLate)
+        stageDestinations();
 
     SPGPU_STAMP(5);
     /* ---- the per-sub-group state of a lane, and the stage loads --------------------------------------------------- */
@@ -492,6 +498,8 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
         for (int q = 0; q < ROUND; ++q)
             if (threadIdx.x + q * BLOCK < pieces)
                 w[q] = loadPackElementAligned<T, PIECE>(from + (size_t)(threadIdx.x + q * BLOCK) * PIECE);
+        if (a.stageLate)
+            stageDestinations(); /* under the tile's and the first stages' round trip */
 #pragma unroll
         for (int q = 0; q < ROUND; ++q)
             if (threadIdx.x + q * BLOCK < pieces)

@@ -43,6 +43,7 @@ template <typename T> struct SlabArgs {
     int pipeRanges;              /* pipeSpmvKernel: ranges per workgroup */
     int avgNnzPerRow;            /* the caller's hint (0: none) */
     int split;                   /* raggedSpmvKernel: columns per chunk of a split sub-group (0: none) */
+    int stageLate;               /* raggedSpmvKernel: the destinations are staged under the tile's round trip (SPGPU_STAGE_LATE=0: before the first requests) */
     /* raggedSpmvKernel<..., PLAN> (planned_spmv.hip): the matrix's plan (spgpu_internal.h) */
     const SpgpuPlanBlock* planBlocks; /* [planMainBlocks] */
     const int* planDeepSubs;          /* [planDeep] sub-groups that get workgroups of their own, ascending */

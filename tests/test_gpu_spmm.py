@@ -252,3 +252,36 @@ def test_spmm_hack_sizes_off_the_strip_path(gpu, letter, hs):
                               mat.base, count, count, count)
         torch.cuda.synchronize()
         assert dZ.cpu().numpy().tobytes() == O.hell_spmm(hell, X, Y, 2.0, 0.25).tobytes()
+
+
+@pytest.mark.parametrize("letter", ["D", "S"])
+def test_band_wavefronts_and_their_neighbours(gpu, letter):
+    """Round 4: wavefronts whose 64 rows form a band through all their columns take the sliding-window loop of the strip kernel
+    (hell_spmm.hip, BAND).  The banded test matrix wraps its columns at both ends, so its first and last wavefronts are NOT bands and
+    run the general loop beside band wavefronts of the same workgroup; then a matrix with scattered columns is copied over the same
+    arrays (no wavefront qualifies).  Every call: the oracle's bits (beta != 0, 16 right-hand sides)."""
+    import torch
+    from spgpu_amd import capi, synth
+    n, k, L = 40_000 // 32 * 32, 16, 32
+    band = synth.hell_uniform_on_device(n, L, "banded", letter, 32, seed=5)
+    scat = synth.hell_uniform_on_device(n, L, "random", letter, 32, seed=6)
+    X = synth.device_vector(n * k, letter, 7).view(n, k)
+    Y = synth.device_vector(n * k, letter, 8).view(n, k)
+    torch.cuda.synchronize()
+    xs, ys = X.cpu().numpy(), Y.cpu().numpy()
+    want = {name: O.hell_spmm(synth.hell_rows_to_host(h, 0, n), xs, ys, 1.5, -0.25) for name, h in (("band", band), ("scat", scat))}
+    live = dict(band)
+
+    def run(expect):
+        Z = torch.full_like(Y, float("nan"))
+        capi.hellspmm[letter](gpu, _p(Z), _p(Y), capi.scalar(letter, 1.5), _p(live["cM"]), _p(live["rP"]), 32, _p(live["hack_offsets"]),
+                              _p(live["rS"]), None, L, n, _p(X), capi.scalar(letter, -0.25), 0, k, k, k)
+        torch.cuda.synchronize()
+        assert Z.cpu().numpy().tobytes() == want[expect].tobytes(), expect
+
+    for _ in range(2):
+        run("band")
+    live["cM"].copy_(scat["cM"])
+    live["rP"].copy_(scat["rP"])
+    torch.cuda.synchronize()
+    run("scat")
