@@ -40,21 +40,21 @@ extern "C" {
 #endif
 
 /*
- * The deep list.  An ELL/HELL SpMV that is given a row order (rIdx) hands the columns beyond SPGPU_DEEP_CAP of its deepest
- * 32-row sub-groups to two small kernels through a list the handle owns (one per stream, 8 192 sub-groups / 20 480 items of 64
- * columns).  A matrix with more such sub-groups than the list holds is still multiplied correctly -- the surplus is summed by
- * the main kernel -- but WHICH sub-groups are surplus depends on the order in which workgroups register, and they are added
- * in the plain order of the kernel, not in the deep order: for such a call z is within the tolerance of every other form but
- * is not reproducible bit for bit from run to run, and is not the bit pattern the oracle restates.  spgpuDeepListOverflows
- * says how many completed calls of the handle that was true for (0 for every matrix the tests and benches use, whose long
- * rows were set aside by spgpuOellOrderDevice; a matrix ordered with longRows = 0 can overflow).  Remedy: a larger
- * SPGPU_DEEP_CAP, or an order that sets the long rows aside.
+ * The deep list.  Until a matrix has its plan (below), an ELL/HELL SpMV that is given a row order (rIdx) hands the columns beyond
+ * SPGPU_DEEP_KEEP of its 32-row sub-groups deeper than SPGPU_DEEP_CAP to two small kernels through a list the handle owns (one per
+ * stream, 8 192 sub-groups / 20 480 items of 64 columns).  A matrix with more such sub-groups than the list holds is multiplied
+ * all the same and, since round 4, TO THE SAME BITS: a sub-group that finds the list full is worked off by its own workgroup,
+ * behind that workgroup's stream, in the chunks and the order of the deep kernels (csrc/deep_rows.hip.h) -- which sub-groups
+ * are surplus depends on scheduling, their sums do not.  Only speed suffers (those workgroups live longer).
+ * spgpuDeepListOverflows says how many completed calls of the handle overflowed (0 for every matrix the tests and benches
+ * use, whose long rows were set aside by spgpuOellOrderDevice; a matrix ordered with longRows = 0 can overflow on its first
+ * calls; planned calls have no list).
  */
 int spgpuDeepListOverflows(spgpuHandle_t handle);
 /* The handle keeps a deep list for each of 8 streams.  A ninth stream takes over the list of the least recently used stream
  * whose calls have all finished (spgpuDeepListsRecycled counts those hand-overs); while none is idle, an ordered SpMV on a stream
- * without a list runs the stateless kernel (csrc/share_spmv.hip.h) -- correct, a different order of additions, slower --
- * and spgpuDeepListFallbacks counts those calls. */
+ * without a list runs the same kernel family without state (csrc/planned_spmv.hip: the matrix' plan if it is ready, else no plan
+ * at all) -- slower, the SAME bits -- and spgpuDeepListFallbacks counts those calls. */
 int spgpuDeepListFallbacks(spgpuHandle_t handle);
 int spgpuDeepListsRecycled(spgpuHandle_t handle);
 
