@@ -38,6 +38,7 @@ static void deepListFor(SpgpuPrivateHandle* h, hipStream_t stream)
                 h->deepStream[h->deepStreams] = stream;
                 h->deepIdle[h->deepStreams] = idle;
                 h->deepUsed[h->deepStreams] = 0;
+                h->deepPinned[h->deepStreams] = 0;
                 h->deepClock[h->deepStreams] = ++h->deepTick;
                 h->deepStreams += 1;
             } else {
@@ -53,8 +54,8 @@ static void deepListFor(SpgpuPrivateHandle* h, hipStream_t stream)
          * carries over from call to call. */
         int pick = -1;
         for (int i = 0; i < h->deepStreams; ++i) {
-            if (h->deepStream[i] == h->pub.defaultStream)
-                continue; /* the default stream always comes back (spgpuSetStream(h, 0)) */
+            if (h->deepStream[i] == h->pub.defaultStream || h->deepPinned[i])
+                continue; /* the default stream always comes back (spgpuSetStream(h, 0)); a captured graph may replay at any time */
             if (h->deepUsed[i] && !spgpuEventDone(h->deepIdle[i]))
                 continue;
             if (pick < 0 || h->deepClock[i] < h->deepClock[pick])
@@ -290,6 +291,16 @@ spgpuStatus_t spgpuDeepScratch(spgpuHandle_t pHandle, SpgpuDeepList* list)
     list->partials = base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES;
     list->itemSums = base + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES + DEEP_PARTIAL_BYTES;
     return SPGPU_SUCCESS;
+}
+
+void spgpuDeepListPin(spgpuHandle_t pHandle)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    pthread_mutex_lock(&h->formLock);
+    for (int i = 0; i < h->deepStreams; ++i)
+        if (h->deepStream[i] == h->pub.currentStream)
+            h->deepPinned[i] = 1;
+    pthread_mutex_unlock(&h->formLock);
 }
 
 int* spgpuAnalyseWords(spgpuHandle_t pHandle)

@@ -1294,8 +1294,15 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
         const bool deepKernels = launchRagged<T, WIDE, IS_HELL, true>(stream, a, shape, form != SPGPU_SPMV_FORM_GATHER);
         if (deepPossible && deepKernels)
             launchDeep<T, WIDE, IS_HELL>(stream, a);
-        if (list.idle)
-            (void)hipEventRecord(list.idle, stream); /* complete = the list has no user (core.c: a list may change hands) */
+        if (list.idle) {
+            /* complete = the list has no user (core.c: a list may change hands) -- unless this launch is being captured: a graph
+             * carries the list's addresses and may be replayed at any time, so the list stays with this stream for good */
+            hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &capturing) == hipSuccess && capturing == hipStreamCaptureStatusNone)
+                (void)hipEventRecord(list.idle, stream);
+            else
+                spgpuDeepListPin(handle);
+        }
         return;
     }
     if (prepared)

@@ -44,6 +44,7 @@ typedef struct SpgpuPrivateHandle {
     hipStream_t deepStream[SPGPU_DEEP_STREAMS];
     hipEvent_t deepIdle[SPGPU_DEEP_STREAMS];  /* recorded behind the deep kernels of the list's latest call: complete = nobody uses the list */
     int deepUsed[SPGPU_DEEP_STREAMS];         /* the event has been recorded at least once */
+    int deepPinned[SPGPU_DEEP_STREAMS];       /* a captured launch carries this list's addresses: it never changes hands */
     unsigned deepClock[SPGPU_DEEP_STREAMS];   /* last handed out (the least recently used idle list changes hands) */
     unsigned deepTick;
     int deepStreams;
@@ -104,6 +105,8 @@ typedef struct SpgpuDeepList {
 } SpgpuDeepList;
 /* Device pointers of the current stream's list, or SPGPU_UNSUPPORTED when that stream has none. */
 spgpuStatus_t spgpuDeepScratch(spgpuHandle_t h, SpgpuDeepList* list);
+/* The current stream's list has gone into a captured graph: it stays with that stream for the handle's lifetime. */
+void spgpuDeepListPin(spgpuHandle_t h);
 
 /*
  * The plan of one matrix with a row order (csrc/planned_spmv.hip; the north_star target).  The queue kernel for ordered rows
@@ -163,7 +166,7 @@ void spgpuPlanRetire(spgpuHandle_t h, SpgpuSpmvPlan* plan);
 static inline int spgpuEventDone(hipEvent_t event)
 {
     const hipError_t said = hipEventQuery(event);
-    if (said == hipErrorNotReady && hipPeekAtLastError() == hipErrorNotReady)
+    if (said != hipSuccess && hipPeekAtLastError() == said) /* "not ready" (or: recorded inside a capture) is this poll's business only */
         (void)hipGetLastError();
     return said == hipSuccess;
 }
