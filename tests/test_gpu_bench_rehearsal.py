@@ -29,6 +29,9 @@ def test_two_ranks_on_one_gpu(gpu, exchange, pattern):
     assert "MISMATCH" not in out["parity"] and "oracle" in out["parity"]
     assert out["config"]["rows_total"] == 400000
     assert "SpMM" in out["metric"] and "2 GPUs" in out["metric"]
+    # first-contact diagnostics (round 4): every rank checked its own rows against the oracle, and said so to the others
+    assert out["spmm"]["rccl_ranks_seen"] == 2 and out["spmm"]["ranks_whose_window_matches_the_oracle"] == 2
+    assert out["spmm"]["exchange_bytes_per_rank"]["allgather"] == 200000 * 16 * 8
     if exchange == "needed":
         assert out["spmm"]["needed_rows_received_per_rank"] == 31        # 16 rows below the block, 15 above (wrapped band)
         assert out["spmm"]["allgather_step_ms"] > 0 and out["as_named_allgather"]["value"] > 0
