@@ -653,6 +653,25 @@ def run_spmv(args, rank, world):
             a2 = hell_algorithmic_bytes(h["nnz"], h["rows"], h["cols"], hacks, beta_nonzero=True)
             extras[f"{args.pattern}_beta0.5"] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(a2 / t * 1e-9, 1),
                                                       frac=round(a2 / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4), form=form_ran(handle))
+            # the headline launches once more with the arrays in allocations of their own, `--placements` times: how far does the
+            # placement of the caller's arrays move THIS kernel on this card?  (`value` stays what the contract
+            # says: the K timed steps above, on the arrays as they were built.)
+            if args.placements > 0:
+                moved = []
+                for _ in range(args.placements):
+                    own = OwnAllocations(dict(cM=h["cM"], rP=h["rP"], hack_offsets=h["hack_offsets"], rS=h["rS"], x=x, z=z))
+                    try:
+                        torch.cuda.synchronize()
+                        placed = lambda own=own: capi.hellspmv["D"](handle, own["z"], None, C.c_double(1.0), own["cM"], own["rP"], h["hack_size"],
+                                                                    own["hack_offsets"], own["rS"], None, args.nnz_per_row, h["rows"], own["x"],
+                                                                    C.c_double(0.0), 0)
+                        moved.append([round(v, 4) for v in timed_blocks(stream, placed)])
+                    finally:
+                        torch.cuda.synchronize()
+                        own.free()
+                every = [v for blocks in moved for v in blocks]
+                out["roofline"]["placements_kernel_ms"] = moved
+                out["roofline"]["placements_frac"] = {k: round(alg / (v * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4) for k, v in (("best", min(every)), ("worst", max(every)))}
             out["cpu_baseline"] = cpu_baseline(h, x, args.cpu_seconds)
             if vendor() is not None:
                 try:
