@@ -123,6 +123,7 @@ def run(h, label, forms):
         knobs = [(part.split("=")[0], part.split("=")[1].split(",")) for part in os.environ["EXP_SWEEP"].split(";")]
         combos = list(itertools.product(*[values for _, values in knobs]))
         seen = {c: [] for c in combos}
+        before = {name: os.environ.get(name) for name, _ in knobs}
         for rep in range(int(os.environ.get("EXP_SWEEP_REPS", "3"))):
             for combo in combos:
                 for (name, _), value in zip(knobs, combo):
@@ -139,6 +140,12 @@ def run(h, label, forms):
                     b.record(stream)
                 b.synchronize()
                 seen[combo].append(a.elapsed_time(b) / 20)
+        for name, value in before.items():      # the next matrix is run (and checked) with the knobs as they were
+            if value is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = value
+        capi.spgpuTuningReload()
         for combo in combos:
             ts = seen[combo]
             print(f"    sweep {label[:40]:40s} " + " ".join(f"{n}={v}" for (n, _), v in zip(knobs, combo)) + "  " + " ".join(f"{t:.4f}" for t in ts)
