@@ -993,7 +993,7 @@ def measure_spmm(args, rank, world, handle, stream, dev, steps, warmup):
         torch.cuda.synchronize()
         return a.elapsed_time(b) / reps * 1e-3
 
-    t_compute = timed(products_only, 10)
+    t_compute = sorted(timed(products_only, 10) for _ in range(3))[1]   # median of three blocks of 10
     t_gather = timed(gather_only, 10) if distributed and (split or world > 1) else 0.0
     t_needed = timed(needed_only, 10) if both and distributed else 0.0
     # the other exchange's step, measured in the same process (same products; what differs is what moves)
