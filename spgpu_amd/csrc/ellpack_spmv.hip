@@ -991,6 +991,7 @@ __device__ unsigned long long* spgpuTraceBuffer;
 #endif
 #include "ragged_spmv.hip.h"
 #ifdef SPGPU_TUNING_VARIANTS
+#include "slide_spmv.hip.h"
 #include "share_spmv.hip.h"
 #include "pipe_spmv.hip.h"
 #endif
@@ -1197,6 +1198,22 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
         }
         form = SPGPU_SPMV_FORM_AUTO;
     }
+#ifdef SPGPU_TUNING_VARIANTS
+    if (tune->slide && form != SPGPU_SPMV_FORM_SWEEP) {
+        /* experiment (SPGPU_SLIDE=1, lab build only; slide_spmv.hip.h, profiles/r04_exp_slide_tile.txt): the x tile moves along with
+         * the slab columns; 8-byte elements, 16-byte slab accesses, no row order.  One phase, no whole-wave tail rows: the order
+         * of additions of the SWEEP form. */
+        if constexpr (sizeof(T) == 8) {
+            if (wideOk && !a.rIdx && tune->spmvVariant < 1 && !prepared) {
+                a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
+                a.feedback = nullptr;
+                spgpuNoteSpmvForm(handle, SPGPU_SPMV_FORM_XTILE);
+                launchSlide<T, WIDE, IS_HELL>(stream, a);
+                return;
+            }
+        }
+    }
+#endif
     const bool tiled = form == SPGPU_SPMV_FORM_XTILE && (variant == 13 || variant == 21 || variant == 22);
     /* Deep split (see slabSpmvKernel, DEEP): on when the caller passes a row order -- rows ordered by length are what
      * one does to a ragged matrix, and then whole hacks are deep -- or when SPGPU_DEEP_SPLIT says so. */
