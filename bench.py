@@ -698,17 +698,18 @@ def run_spmv(args, rank, world):
                     except Exception as error:  # noqa: BLE001
                         extras[pattern]["vendor_context"] = repr(error)
                 if pattern == "random":
-                    # the caller's hint for scattered columns that ascend inside a row (include/spgpu/tuning.h, SWEEP):
-                    # 32 rows per lane carried through the columns in step; uniform rows: the same bits as the default
-                    capi.spgpuSetSpmvForm(handle, capi.FORM_SWEEP)
+                    # AUTO takes the SWEEP form here since round 4 (scattered columns that ascend inside the rows: 32 rows per lane
+                    # carried through the columns in step, include/spgpu/tuning.h; the same bits as the gather kernel).  For the
+                    # record, the gather kernel on the same arrays:
+                    capi.spgpuSetSpmvForm(handle, capi.FORM_GATHER)
                     time_launches(stream, step, 3)
                     t = time_launches(stream, step, 20) / 20
                     z.zero_()
                     torch.cuda.synchronize()
                     time_launches(stream, step, 1)
-                    extras["random_form_sweep"] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
-                                                       frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4), form=form_ran(handle),
-                                                       parity=spot_check_hell(h, x, y, z, 1.0, 0.0))
+                    extras["random_form_gather"] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
+                                                        frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4), form=form_ran(handle),
+                                                        parity=spot_check_hell(h, x, y, z, 1.0, 0.0))
                     capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
             out["variants"] = extras
             # the same banded workload in the other three value types (untimed extras, each checked against the oracle)

@@ -99,8 +99,8 @@ int spgpuTuningVariantsBuilt(void);
  *   AUTO    the library decides per matrix: sample wavefronts report what they saw (consecutive columns in neighbouring
  *           rows / columns inside a window that fits an LDS tile / scattered) and the next launch on the same arrays
  *           uses it.  A first call runs the strip-capable kernel, whose own wavefronts report; the other forms are
- *           looked at again by a three-wavefront probe with every fourth call (another matrix may have come to live
- *           at the address).  spgpuHellSpmvForm / spgpuEllSpmvForm below give the same answer at once, to keep.
+ *           looked at again by a three-wavefront probe with their first and then every fourth call (another matrix may
+ *           have come to live at the address).  spgpuHellSpmvForm / spgpuEllSpmvForm below give the same answer at once, to keep.
  *   GATHER  one global load per nonzero.
  *   STRIPS  the x values of a lane's consecutive rows with ONE 16-byte load where those rows name consecutive
  *           columns (stencil and band matrices in natural order); falls back to gathers stage by stage.
@@ -108,14 +108,20 @@ int spgpuTuningVariantsBuilt(void);
  *           (columns near the diagonal but not consecutive; length-sorted rows used through rIdx); entries outside
  *           the tile are gathered from global memory.
  *
- *   SWEEP   (never chosen by AUTO) for matrices whose columns are scattered over all of x but ascend inside a row: a
- *           lane carries 32 rows (16 for complex fp64) through the slab columns in step, so that at any moment the rows
- *           in flight gather from the same quantile of x and meet in L2 (10 M x 32 scattered, fp64: 4.5 ms against
- *           5.85).  A row's products are added in ascending k -- the reference's one-thread-per-row order
- *           (hell_spmv_base_template.cuh:104-215) -- which is NOT the bit pattern of the other forms for fp32, for complex
- *           fp64 and on rows short enough to engage the whole-wave tail; without rIdx only (with rIdx: as AUTO).  On
- *           matrices with locality between neighbouring rows, or with rows of very unequal length (a lane walks its 32
- *           rows to the longest of them), this form is several times SLOWER than the others.
+ *   SWEEP   for matrices whose columns are scattered over all of x but ascend inside a row: a lane carries 32 rows (16 for
+ *           complex fp64) through the slab columns in step, so that at any moment the rows in flight gather from the same
+ *           quantile of x and meet in L2 (10 M x 32 scattered, fp64: 4.66 ms against 6.0).  Without rIdx only (with rIdx: as
+ *           AUTO).  On matrices with locality between neighbouring rows, or with rows of very unequal length (a lane walks
+ *           its 32 rows to the longest of them), this form is several times SLOWER than the others.
+ *           Order of additions: for the 8-byte types (fp64, complex fp32) the bits of AUTO / GATHER / STRIPS / XTILE -- ascending
+ *           k, and the last rows of a 128-row group finished by the whole wavefront exactly where their default kernel does it;
+ *           for fp32 and complex fp64 a row's products in ascending k, the reference's one-thread-per-row order
+ *           (hell_spmv_base_template.cuh:104-215), which is NOT the bit pattern of their other forms.
+ *           AUTO takes this form by itself for the 8-byte types (since round 4) when the three-wavefront probe finds, in two of
+ *           its three groups of rows: columns reaching over half the matrix' rows and more (the matrix is taken to be about
+ *           square: no call says how long x is), ascending in every sampled row, rows about equally long (slots of the group
+ *           <= 1.5 x its nonzeros) -- and the matrix has 4 Mi rows or more (the form wants a grid that fills the chip).
+ *           SPGPU_AUTO_SWEEP=0 keeps AUTO out of it.
  *
  * The hint applies to every later SpMV call on the handle, from any thread; SPGPU_X_STRIPS / SPGPU_X_TILE in the
  * environment override it.
@@ -140,7 +146,7 @@ int spgpuGetLastSpmvForm(spgpuHandle_t handle);
  *
  * Three wavefronts look at the column indices of three groups of rows (near the quarter points of the matrix) on the
  * handle's current stream; the call WAITS for them (it synchronises that stream) and returns SPGPU_SPMV_FORM_STRIPS,
- * _XTILE or _GATHER (AUTO if the device call failed).  One analysis of a handle at a time.  rP / hackOffsets / rS: the
+ * _XTILE, _GATHER or -- where AUTO would take it -- _SWEEP (AUTO if the device call failed).  One analysis of a handle at a time.  rP / hackOffsets / rS: the
  * device arrays of the SpMV call; rS may be NULL for ELL (every row maxNnzPerRow long).
  */
 int spgpuHellSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int hackSize, const int* hackOffsets, const int* rS, int rows,

@@ -472,6 +472,7 @@ void spgpuTuningReload(void)
     t.l1Blocks = envInt("SPGPU_L1_BLOCKS", 0);
     t.xStrips = envInt("SPGPU_X_STRIPS", -1);
     t.xTile = envInt("SPGPU_X_TILE", -1);
+    t.autoSweep = envInt("SPGPU_AUTO_SWEEP", 1);
     t.slide = envInt("SPGPU_SLIDE", 0);
     t.xTileShape = envInt("SPGPU_X_TILE_SHAPE", 0);
     t.deepSplit = envInt("SPGPU_DEEP_SPLIT", -1);

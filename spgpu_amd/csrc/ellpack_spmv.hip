@@ -835,9 +835,34 @@ __global__ __launch_bounds__(kWave) void formProbeKernel(const SlabArgs<T> a)
     highest = waveMax(highest);
     const long long span = __ballot(below) != 0ull ? (1ll << 40) : (highest < lowest ? 0ll : (long long)highest - lowest + 1);
     const int asStrips = firstBad == 0x7fffffff ? groupLongest : firstBad / STEP * STEP; /* whole stages of strips in front */
+    /* 4 = a matrix for the SWEEP form: the columns of the group reach over half of x and more (the matrix is taken to be about
+     * square: the API does not say how long x is), ascend inside every sampled row (its first 64 entries), and the rows are about
+     * equally long (rows walked in step wait for the longest) */
+    bool sweepable = false;
+    if constexpr (PH == 1 && sizeof(T) == 8) {
+        bool ascends = true;
+        int total = 0;
+#pragma unroll
+        for (int t = 0; t < RPL; ++t) {
+            total += len[t];
+            const int look = len[t] < 64 ? len[t] : 64;
+            int before = -0x7fffffff - 1;
+            for (int k = 0; k < look; ++k) {
+                const int c = a.rP[slab + t + (long long)k * a.idxStride];
+                ascends &= c >= before;
+                before = c;
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1)
+            total += laneXor(total, m);
+        const long long slots = (long long)groupLongest * GROUP_ROWS;
+        sweepable = __ballot(!ascends) == 0ull && span < (1ll << 40) && 2 * span >= (long long)a.rows && groupLongest >= 2 * STEP &&
+                    2 * slots <= 3 * (long long)total;
+    }
     if (lane == 0 && a.feedback)
         a.feedback[blockIdx.x] = a.feedbackTag | ((RPL > 1 && 2 * asStrips >= groupLongest && groupLongest > STEP) ? 2
-                                                  : (groupLongest > STEP && span <= a.tileSpanLimit ? 3 : 1)); /* one stage of rows: no tile */
+                                                  : (groupLongest > STEP && span <= a.tileSpanLimit ? 3 : (sweepable ? 4 : 1))); /* one stage of rows: no tile */
 }
 
 /*
@@ -897,24 +922,34 @@ __global__ __launch_bounds__(kWave) void orderedProbeKernel(const int* rP, const
 }
 
 /*
- * SWEEP form (include/spgpu/tuning.h; chosen by the caller, never by AUTO): for matrices whose columns are scattered over
- * all of x but ascend inside a row.  A lane owns PACKS packs of VEC neighbouring rows (32 rows for 4- and 8-byte elements)
- * and carries all of them through the slab columns in step; the grid is small enough to be resident at once and walks
- * the rows with a tile stride.  At any moment the rows in flight are at about the same k, i.e. they gather from about the
- * same quantile of x, and meet in L2: 10 M x 32 scattered, fp64: L2 hits 22 M -> 54 M of 320 M gathers, 5.85 -> 4.5 ms.
- * A row's products are added in ascending k (orc_?hellspmv / orc_?ellspmv with one phase), the reference's
- * one-thread-per-row order (hell_spmv_base_template.cuh:104-215).  No LDS; coefficient and index streams non-temporal.
+ * SWEEP form (include/spgpu/tuning.h; the caller's hint, and AUTO's choice for 8-byte elements when the probe finds such a
+ * matrix): for matrices whose columns are scattered over all of x but ascend inside a row.  A lane owns PACKS packs of VEC
+ * neighbouring rows (32 rows for 4- and 8-byte elements) and carries all of them through the slab columns in step; the grid
+ * is small enough to be resident at once and walks the rows with a tile stride.  At any moment the rows in flight are at
+ * about the same k, i.e. they gather from about the same quantile of x, and meet in L2: 10 M x 32 scattered, fp64: L2 hits
+ * 22 M -> 54 M of 320 M gathers, 5.85 -> 4.5 ms.  No LDS; coefficient and index streams non-temporal.
+ *
+ * Order of additions.  TAIL = false: a row's products in ascending k (orc_?hellspmv / orc_?ellspmv with one phase), the
+ * reference's one-thread-per-row order (hell_spmv_base_template.cuh:104-215).  TAIL = true (the types whose default kernel
+ * walks whole rows: 8-byte elements): exactly that kernel's order -- pack u of a wavefront is the 64 * VEC consecutive rows
+ * one of its wavefronts owns, the group hands its last rows to the whole wavefront at the slab column at which that
+ * kernel would (first multiple of 8 with at most tailLanes lanes still busy; slabSpmvKernel, TAIL), and they are finished
+ * the same way: so AUTO may pick this form without changing a bit of z.
  */
-template <typename T, int VEC, int PACKS, bool IS_HELL, bool HAS_BETA>
+template <typename T, int VEC, int PACKS, bool IS_HELL, bool HAS_BETA, bool TAIL>
 __global__ __launch_bounds__(kBlockThreads) void sweepSpmvKernel(const SlabArgs<T> a)
 {
     const long long packs = ((long long)a.rows + VEC - 1) / VEC;
     constexpr long long TILE = (long long)kBlockThreads * PACKS;
+    constexpr int TAIL_STRIDE = 8; /* the stage of the default kernel of the 8-byte types (launchSlabFamily: 1 phase x 8 columns) */
+    const int lane = threadIdx.x & (kWave - 1);
     for (long long base = (long long)blockIdx.x * TILE; base < packs; base += (long long)gridDim.x * TILE) {
         T sums[PACKS][VEC];
         int len[PACKS][VEC];
         long long slot[PACKS];
+        int tailFrom[PACKS]; /* TAIL: pack u walks the slab columns below tailFrom[u] here (wavefront-uniform) */
         int longest = 0;
+        unsigned tails = 0u; /* TAIL: packs whose wavefront has tail rows (wavefront-uniform) */
 #pragma unroll
         for (int u = 0; u < PACKS; ++u) {
             const long long row = (base + u * kBlockThreads + threadIdx.x) * VEC;
@@ -928,12 +963,29 @@ __global__ __launch_bounds__(kBlockThreads) void sweepSpmvKernel(const SlabArgs<
                     slot[u] = row;
                 }
             }
+            int packLongest = 0;
 #pragma unroll
             for (int t = 0; t < VEC; ++t) {
                 sums[u][t] = zeroOf<T>();
                 len[u][t] = row + t < a.rows ? (a.rS ? a.rS[row + t] : a.maxNnz) : 0;
-                longest = len[u][t] > longest ? len[u][t] : longest;
+                packLongest = len[u][t] > packLongest ? len[u][t] : packLongest;
             }
+            tailFrom[u] = 0x7fffffff;
+            if constexpr (TAIL) {
+                const int groupLongest = waveMax(packLongest);
+                for (int kBase = 0; kBase < groupLongest; kBase += TAIL_STRIDE) {
+                    if (__popcll(__ballot(kBase < packLongest)) <= a.tailLanes) {
+                        tailFrom[u] = kBase;
+                        tails |= 1u << u;
+                        break;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < VEC; ++t)
+                    len[u][t] = len[u][t] < tailFrom[u] ? len[u][t] : tailFrom[u];
+                packLongest = packLongest < tailFrom[u] ? packLongest : tailFrom[u];
+            }
+            longest = packLongest > longest ? packLongest : longest;
         }
         for (int k = 0; k < longest; ++k) {
             Pack<T, VEC> v[PACKS];
@@ -962,6 +1014,64 @@ __global__ __launch_bounds__(kBlockThreads) void sweepSpmvKernel(const SlabArgs<
                     const T xv = a.x[use ? col : 0];
                     if (use)
                         sums[u][t] = mulAdd(v[u].v[t], xv, sums[u][t]);
+                }
+            }
+        }
+        if constexpr (TAIL) {
+            /* the rows a group handed over: one at a time by the WHOLE wavefront, as slabSpmvKernel's tail does -- lane l takes
+             * the entries tailFrom + l, + 64, ..., the 64 partial sums are combined with lane-xor shuffles and added to the
+             * owner's running sum */
+            if (tails != 0u) { /* wavefront-uniform */
+#pragma unroll
+                for (int u = 0; u < PACKS; ++u) {
+                    if (!(tails & (1u << u)))
+                        continue;
+                    const long long row = (base + u * kBlockThreads + threadIdx.x) * VEC;
+                    int full[VEC], fullLongest = 0; /* the lengths again: len[] was cut at tailFrom */
+#pragma unroll
+                    for (int t = 0; t < VEC; ++t) {
+                        full[t] = row + t < a.rows ? (a.rS ? a.rS[row + t] : a.maxNnz) : 0;
+                        fullLongest = full[t] > fullLongest ? full[t] : fullLongest;
+                    }
+                    const int from = tailFrom[u];
+                    unsigned long long pending = __ballot(from < fullLongest);
+                    while (pending) { /* wavefront-uniform */
+                        const int owner = __ffsll((long long)pending) - 1;
+                        pending &= pending - 1;
+                        const long long ownerSlot = __shfl(slot[u], owner, kWave);
+#pragma unroll
+                        for (int t = 0; t < VEC; ++t) {
+                            const int rowLen = __shfl(full[t], owner, kWave);
+                            if (rowLen <= from)
+                                continue;
+                            const T* __restrict__ rowVals = a.cM + ownerSlot + t;
+                            const int* __restrict__ rowIdxs = a.rP + ownerSlot + t;
+                            T part = zeroOf<T>();
+                            for (int k0 = from + lane; k0 < rowLen + (kTailUnroll - 1) * kWave; k0 += kTailUnroll * kWave) {
+                                T tv[kTailUnroll];
+                                int tc[kTailUnroll];
+#pragma unroll
+                                for (int q = 0; q < kTailUnroll; ++q) {
+                                    const int k = k0 + q * kWave;
+                                    const bool in = k < rowLen;
+                                    tv[q] = in ? rowVals[(long long)k * a.valStride] : zeroOf<T>();
+                                    tc[q] = in ? rowIdxs[(long long)k * a.idxStride] - a.baseIndex : -1;
+                                }
+                                T tx[kTailUnroll];
+#pragma unroll
+                                for (int q = 0; q < kTailUnroll; ++q)
+                                    tx[q] = a.x[tc[q] >= 0 ? tc[q] : 0];
+#pragma unroll
+                                for (int q = 0; q < kTailUnroll; ++q)
+                                    part = pick(tc[q] >= 0, mulAdd(tv[q], tx[q], part), part);
+                            }
+#pragma unroll
+                            for (int m = 1; m < kWave; m <<= 1)
+                                part = add(part, laneXor(part, m));
+                            if (lane == owner)
+                                sums[u][t] = add(sums[u][t], part);
+                        }
+                    }
                 }
             }
         }
@@ -1073,18 +1183,22 @@ static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
     }
 }
 
-/* SWEEP: 32 rows per lane (16 for 16-byte elements), at most 2 048 workgroups. */
+constexpr int kAutoSweepRows = 4 * 1024 * 1024; /* AUTO: the SWEEP form wants a grid that fills the chip (8 192 rows per workgroup) */
+
+/* SWEEP: 32 rows per lane (16 for 16-byte elements), at most 2 048 workgroups.  8-byte elements add in the order of their
+ * default kernel (whole-wave tail rows), the others in one phase. */
 template <typename T, int VEC, bool IS_HELL>
 static void launchSweep(hipStream_t stream, const SlabArgs<T>& a)
 {
     constexpr int PACKS = sizeof(T) == 16 ? 16 : 32 / VEC;
+    constexpr bool TAIL = sizeof(T) == 8;
     const long long packs = ((long long)a.rows + VEC - 1) / VEC;
     long long blocks = (packs + (long long)kBlockThreads * PACKS - 1) / ((long long)kBlockThreads * PACKS);
     blocks = blocks > 2048 ? 2048 : blocks;
     if (isNotZero(a.beta))
-        hipLaunchKernelGGL((sweepSpmvKernel<T, VEC, PACKS, IS_HELL, true>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, a);
+        hipLaunchKernelGGL((sweepSpmvKernel<T, VEC, PACKS, IS_HELL, true, TAIL>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL((sweepSpmvKernel<T, VEC, PACKS, IS_HELL, false>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, a);
+        hipLaunchKernelGGL((sweepSpmvKernel<T, VEC, PACKS, IS_HELL, false, TAIL>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, a);
 }
 
 /* Right behind a DEEP kernel.  Fixed grids (the number of items is known on the device only): with nothing
@@ -1339,7 +1453,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
         return;
     }
 #endif
-    bool strips = false, autoTile = false, probeBehind = false;
+    bool strips = false, autoTile = false, autoSweep = false, probeBehind = false;
     a.feedback = nullptr;
     a.tileSpanLimit = (long long)(32768 / sizeof(T)) * 5 / 4; /* 1.25 x the default tile (launchTiled, shape 0) */
     if (!narrowVariant && WIDE > 1 && !tiled) {
@@ -1349,26 +1463,41 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
             int calls = 0, tag = 0;
             int* seen = spgpuFormFeedback(handle, a.rP, a.rows, &calls, &tag);
             a.feedbackTag = tag;
-            int gathers = 0, local = 0;
+            int gathers = 0, local = 0, sweeps = 0;
             for (int q = 0; q < 3; ++q) {
                 const int said = spgpuFeedbackSaid(((volatile int*)seen)[q], tag);
                 gathers += said == 1 ? 1 : 0;
                 local += said == 3 ? 1 : 0;
+                sweeps += said == 4 ? 1 : 0;
             }
             /* two of three samples decide: scattered -> gathers; inside a window -> the LDS tile; otherwise (strips, or
              * nothing known yet) the strip-capable kernel */
             autoTile = local >= 2 && tune->spmvVariant < 1 && (variant == 21 || variant == 22);
-            strips = gathers + local < 2;
+            strips = gathers + local + sweeps < 2;
+            /* scattered over all of x, ascending inside the rows, rows about equally long (only the probe says so: answer 4):
+             * the SWEEP form -- same bits as the default kernel of the 8-byte types; it needs rows for a resident grid */
+            autoSweep = sweeps >= 2 && !autoTile && sizeof(T) == 8 && variant == 21 && tune->spmvVariant < 1 && tune->autoSweep != 0 &&
+                        !a.rIdx && a.rows >= kAutoSweepRows;
             a.feedback = seen; /* the strip-capable kernel's sample wavefronts report (it is what a new matrix runs first) */
             /* the other forms do not (see slabSpmvKernel): with every fourth call of theirs three wavefronts look at the
-             * matrix again -- another one may live at this address by now */
-            probeBehind = !strips && calls % 4 == 0;
+             * matrix again -- another one may live at this address by now -- and with the first of them (the samples know
+             * strips, a window and "neither"; whether "neither" is a matrix for the SWEEP form only the probe finds out) */
+            probeBehind = !strips && (calls % 4 == 0 || calls == 1);
         }
     }
 
-    spgpuNoteSpmvForm(handle, (tiled || autoTile) ? SPGPU_SPMV_FORM_XTILE : (strips ? SPGPU_SPMV_FORM_STRIPS : SPGPU_SPMV_FORM_GATHER));
+    spgpuNoteSpmvForm(handle, (tiled || autoTile) ? SPGPU_SPMV_FORM_XTILE
+                                                  : (autoSweep ? SPGPU_SPMV_FORM_SWEEP : (strips ? SPGPU_SPMV_FORM_STRIPS : SPGPU_SPMV_FORM_GATHER)));
     if (probeBehind)
         launchFormProbe<T, IS_HELL>(stream, a, wideOk); /* 3 wavefronts; its answer is for later calls */
+    if (autoSweep) {
+        if constexpr (WIDE > 1) {
+            a.wideIO = alignedTo(a.z, 16) && alignedTo(a.y, 16);
+            a.feedback = nullptr;
+            launchSweep<T, WIDE, IS_HELL>(stream, a);
+            return;
+        }
+    }
     if (!strips)
         a.feedback = nullptr;
     if (!narrowVariant) {
@@ -1616,11 +1745,14 @@ static int analyseForm(spgpuHandle_t handle, const int* rP, int hackSize, const 
     launchFormProbe<T, IS_HELL>(handle->currentStream, a, wide);
     if (hipStreamSynchronize(handle->currentStream) != hipSuccess)
         return SPGPU_SPMV_FORM_AUTO;
-    int strips = 0, local = 0;
+    int strips = 0, local = 0, sweeps = 0;
     for (int q = 0; q < 3; ++q) {
         strips += seen[q] == 2;
         local += seen[q] == 3;
+        sweeps += seen[q] == 4;
     }
+    if (sweeps >= 2 && sizeof(T) == 8 && rows >= kAutoSweepRows) /* where AUTO itself would take it */
+        return SPGPU_SPMV_FORM_SWEEP;
     return strips >= 2 ? SPGPU_SPMV_FORM_STRIPS : (local >= 2 ? SPGPU_SPMV_FORM_XTILE : SPGPU_SPMV_FORM_GATHER);
 }
 

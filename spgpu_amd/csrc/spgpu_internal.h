@@ -202,6 +202,7 @@ typedef struct SpgpuTuning {
     int l1Blocks;    /* 0: kernel default */
     int xStrips;     /* -1: by feedback */
     int xTile;       /* -1: by the handle's hint */
+    int autoSweep;   /* 1: AUTO may pick the SWEEP form (SPGPU_AUTO_SWEEP=0: never) */
     int slide;       /* 0; lab builds: 1 = the moving x tile of slide_spmv.hip.h for 8-byte elements (experiment) */
     int xTileShape;  /* 0 */
     int deepSplit;   /* -1: when rIdx is given */

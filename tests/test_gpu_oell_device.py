@@ -423,6 +423,60 @@ def test_auto_form_settles_on_the_matrix(gpu, pattern, expect):
     assert z[:2048].cpu().numpy().tobytes() == O.default_spmv(sub, x.cpu().numpy(), None, 1.0, 0.0).tobytes()
 
 
+def test_auto_takes_the_sweep_form_for_a_large_scattered_matrix(gpu, tuning):
+    """AUTO and the SWEEP form (include/spgpu/tuning.h): the probe that looks at a matrix in the gather form again also finds out
+    whether its columns reach over all of x, ascend inside the rows and the rows are about equally long; two of three samples
+    saying so select the SWEEP form for the 8-byte types on matrices of 4 Mi rows and more -- the same bits as the gather kernel
+    and as the oracle in the default order.  The analysis call says the same; a 65 536-column window stays with the gathers; and
+    SPGPU_AUTO_SWEEP=0 keeps AUTO out of it."""
+    import torch
+    from spgpu_amd import capi, synth
+    n, nnz = 4 * 1024 * 1024 + 4096, 16
+    x = synth.device_vector(n, "D", 5)
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+
+    def run(h, calls):
+        forms, results = [], []
+        for _ in range(calls):
+            capi.hellspmv["D"](gpu, _dp(z), None, 1.0, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), None, nnz, n,
+                               _dp(x), 0.0, 0)
+            torch.cuda.synchronize()
+            forms.append(capi.spgpuGetLastSpmvForm(gpu))
+            results.append(z[:4096].cpu().numpy().tobytes() + z[-4096:].cpu().numpy().tobytes())
+        return forms, results
+
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    h = synth.hell_uniform_on_device(n, nnz, "random", "D", 32, seed=3)
+    torch.cuda.synchronize()
+    forms, results = run(h, 8)
+    assert forms[-1] == capi.FORM_SWEEP and capi.FORM_SWEEP in forms[:6], forms
+    assert len(set(results)) == 1
+    whole = z.clone()
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_GATHER)
+    try:
+        run(h, 1)
+        assert torch.equal(whole, z)
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    sub = synth.hell_rows_to_host(h, 0, 2048)
+    assert whole[:2048].cpu().numpy().tobytes() == O.default_spmv(sub, x.cpu().numpy(), None, 1.0, 0.0).tobytes()
+    assert capi.spgpuHellSpmvForm(gpu, capi.TYPE_CODE["D"], _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), n, 0) == capi.FORM_SWEEP
+    assert capi.spgpuHellSpmvForm(gpu, capi.TYPE_CODE["S"], _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), n, 0) == capi.FORM_GATHER
+    # the knob
+    tuning(SPGPU_AUTO_SWEEP=0)
+    forms, _ = run(h, 6)
+    assert capi.FORM_SWEEP not in forms, forms
+    tuning(SPGPU_AUTO_SWEEP=1)
+    del h
+    # columns inside a window: scattered for a tile, but nowhere near all of x.  (The arrays may sit where the scattered matrix'
+    # did: AUTO then starts from what it knew of that one and looks again within four calls.)
+    h = synth.hell_uniform_on_device(n, nnz, "window", "D", 32, seed=4)
+    torch.cuda.synchronize()
+    forms, results = run(h, 12)
+    assert capi.FORM_SWEEP not in forms[6:] and forms[-1] == capi.FORM_GATHER, forms
+    assert len(set(results)) == 1
+
+
 def _deep_case(gpu, n, seed):
     """A matrix whose ordered form has deep sub-groups (rows up to 900 entries, cap 256), as a device HELL + host copy."""
     import torch

@@ -249,9 +249,18 @@ def test_streams_come_and_go_lists_change_hands(gpu):
             s = torch.cuda.Stream()
             capi.spgpuSetStream(gpu, C.c_void_p(s.cuda_stream))
             dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            before = (capi.plan_counts(gpu), capi.spgpuDeepListFallbacks(gpu), capi.spgpuDeepListsRecycled(gpu))
             _call(gpu, "D", h, n, dz, None, dx, 1.0, 0.0)
             torch.cuda.synchronize()
-            assert dz.cpu().numpy().tobytes() == want.tobytes()
+            got = dz.cpu().numpy()
+            if got.tobytes() != want.tobytes():      # say what a failure would need to be understood
+                rows = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
+                r_idx = h["rIdx"].cpu().numpy()
+                where = np.empty(n, np.int64)
+                where[r_idx] = np.arange(n)
+                lengths = h["rS"][:n].cpu().numpy()
+                raise AssertionError((_, rows[:8], where[rows][:8], lengths[where[rows]][:8], got[rows][:4], want[rows][:4], before,
+                                      capi.plan_counts(gpu), capi.spgpuDeepListFallbacks(gpu), capi.spgpuDeepListsRecycled(gpu)))
             del s
     finally:
         capi.spgpuSetStream(gpu, None)

@@ -251,9 +251,11 @@ def test_handle_and_streams(gpu):
 @pytest.mark.parametrize("fmt", ["hell", "ell"])
 @pytest.mark.parametrize("n,hack,base", [(1, 32, 0), (77, 32, 1), (5000, 64, 0), (40_003, 32, 0), (700_001, 32, 1)])
 def test_sweep_form_is_the_one_phase_order(gpu, letter, fmt, n, hack, base):
-    """SPGPU_SPMV_FORM_SWEEP (tuning.h): 32 rows per lane carried through the columns in step; a row's products added in
-    ascending k = the oracle with one phase, bit for bit; ragged rows incl. empty ones, rows not a multiple of the pack,
-    beta != 0, in place; and with a row order the hint falls back to the kernels for ordered rows."""
+    """SPGPU_SPMV_FORM_SWEEP (tuning.h): 32 rows per lane carried through the columns in step.  fp32 and complex fp64: a row's
+    products added in ascending k = the oracle with one phase, bit for bit.  The 8-byte types: the bits of their DEFAULT kernel
+    (one phase too, and the last rows of a 128-row group finished by the whole wavefront exactly where that kernel does it) --
+    which is what lets AUTO pick the form.  Ragged rows incl. empty ones and rows long enough for the tail, rows not a multiple
+    of the pack, beta != 0, in place."""
     import torch
     from spgpu_amd import capi, formats, synth
     lengths = np.minimum(synth.power_law_lengths(n, mean=7.0, max_len=90, seed=n), n)
@@ -272,8 +274,19 @@ def test_sweep_form_is_the_one_phase_order(gpu, letter, fmt, n, hack, base):
             torch.cuda.synchronize()
             assert capi.spgpuGetLastSpmvForm(gpu) == capi.FORM_SWEEP
             oracle = O.hell_spmv if fmt == "hell" else O.ell_spmv
-            want = oracle(hell if fmt == "hell" else ell, x, y if beta != 0 else None, alpha, beta, phases=1)
+            host = hell if fmt == "hell" else ell
+            if letter in "DC":
+                want = O.default_spmv(host, x, y if beta != 0 else None, alpha, beta)
+            else:
+                want = oracle(host, x, y if beta != 0 else None, alpha, beta, phases=1)
             assert dz.cpu().numpy().tobytes() == want.tobytes(), (alpha, beta, in_place)
+            if letter in "DC":   # and the default kernel itself says the same
+                capi.spgpuSetSpmvForm(gpu, capi.FORM_GATHER)
+                dg = dy.clone() if in_place else torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+                mat.spmv(gpu, dg, dg if in_place else (dy if beta != 0 else None), alpha, dx, beta)
+                torch.cuda.synchronize()
+                capi.spgpuSetSpmvForm(gpu, capi.FORM_SWEEP)
+                assert torch.equal(dg.view(torch.uint8), dz.view(torch.uint8)), (alpha, beta, in_place)
     finally:
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
 
