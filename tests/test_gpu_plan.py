@@ -249,6 +249,7 @@ def test_streams_come_and_go_lists_change_hands(gpu):
             s = torch.cuda.Stream()
             capi.spgpuSetStream(gpu, C.c_void_p(s.cuda_stream))
             dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            torch.cuda.synchronize()   # the fill runs on torch's stream, the SpMV on the new (non-blocking) one: without this the fill may land on top of z
             before = (capi.plan_counts(gpu), capi.spgpuDeepListFallbacks(gpu), capi.spgpuDeepListsRecycled(gpu))
             _call(gpu, "D", h, n, dz, None, dx, 1.0, 0.0)
             torch.cuda.synchronize()
