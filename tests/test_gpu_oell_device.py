@@ -477,6 +477,41 @@ def test_auto_takes_the_sweep_form_for_a_large_scattered_matrix(gpu, tuning):
     assert len(set(results)) == 1
 
 
+def test_auto_sweep_ell_complex(gpu):
+    """The same choice for ELL and the other 8-byte type (complex fp32): AUTO settles on the SWEEP form for the scattered matrix, and
+    its z is the gather kernel's, byte for byte."""
+    import torch
+    from spgpu_amd import capi, synth
+    n, nnz = 4 * 1024 * 1024 + 4096, 16
+    h = synth.hell_uniform_on_device(n, nnz, "random", "C", 32, seed=9)
+    cM = h["cM"].view(n // 32, nnz, 32).permute(1, 0, 2).reshape(-1).contiguous()     # the same slots as ELL: pitch = n
+    rP = h["rP"].view(n // 32, nnz, 32).permute(1, 0, 2).reshape(-1).contiguous()
+    del h
+    x = synth.device_vector(n, "C", 5)
+    y = synth.device_vector(n, "C", 6)
+    z = torch.empty_like(x)
+    alpha, beta = capi.scalar("C", 0.75), capi.scalar("C", -0.5)
+    torch.cuda.synchronize()
+    call = lambda: capi.ellspmv["C"](gpu, _dp(z), _dp(y), alpha, _dp(cM), _dp(rP), n, n, None, None, nnz, nnz, n, _dp(x), beta, 0)
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    forms = []
+    for _ in range(8):
+        call()
+        torch.cuda.synchronize()
+        forms.append(capi.spgpuGetLastSpmvForm(gpu))
+    assert forms[-1] == capi.FORM_SWEEP, forms
+    swept = z.clone()
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_GATHER)
+    try:
+        call()
+        torch.cuda.synchronize()
+        assert capi.spgpuGetLastSpmvForm(gpu) == capi.FORM_GATHER
+        assert torch.equal(torch.view_as_real(swept).view(torch.int32), torch.view_as_real(z).view(torch.int32))
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+    assert capi.spgpuEllSpmvForm(gpu, capi.TYPE_CODE["C"], _dp(rP), n, None, nnz, n, 0) == capi.FORM_SWEEP
+
+
 def _deep_case(gpu, n, seed):
     """A matrix whose ordered form has deep sub-groups (rows up to 900 entries, cap 256), as a device HELL + host copy."""
     import torch
