@@ -41,6 +41,11 @@ FORMS = {"auto": 0, "gather": 1, "strips": 2, "tile0": 3, "tile1": 3, "tile2": 3
 DEEP_CAP = int(os.environ.get("SPGPU_DEEP_CAP", "256"))
 
 
+def spgpu_lab():
+    """a -DSPGPU_TUNING_VARIANTS build keeps the older kernels for ordered rows selectable (SPGPU_RAGGED=0)"""
+    return bool(capi.spgpuTuningVariantsBuilt()) and os.environ.get("SPGPU_RAGGED", "1") == "0"
+
+
 def shape_of(form, ordered):
     """spmv_tail parameters of the kernel that runs (tests/oracle_api.py slab_shape); a row order switches the deep split on"""
     deep = DEEP_CAP if (ordered and os.environ.get("SPGPU_DEEP_SPLIT", "-1") != "0") or os.environ.get("SPGPU_DEEP_SPLIT") == "1" else 0
@@ -48,7 +53,7 @@ def shape_of(form, ordered):
         return dict(group_rows=64, rows_per_lane=1, step=1, tail_lanes=0, phases=1)      # ascending k, nothing else
     if form.startswith(("share", "pipe")):
         return O.slab_shape(letter, "share")
-    if form.startswith("ragged") or (form == "auto" and ordered):     # with a row order AUTO picks one of the queue kernel's shapes
+    if form.startswith("ragged") or (form in ("auto", "gather") and ordered and not spgpu_lab()):     # with a row order the product runs the queue kernel in every form
         return O.slab_shape(letter, "ragged", 0, deep_cap=deep, split=int(os.environ.get("SPGPU_RAGGED_SPLIT", "-1")))
     if form.startswith("tile"):
         return O.slab_shape(letter, "xtile", int(form[4:]), deep_cap=deep)
@@ -218,7 +223,7 @@ if "powerlaw" in cases:
                                                    order=order is not None, aligned=aligned)
             if aligned and os.environ.get("EXP_ALIGNED") == "check":    # the device order against this file's numpy statement of it
                 assert h["rIdx"].cpu().numpy().tolist() == aligned_order(lengths, *order).tolist()
-            forms = ["gather"] if ((pattern == "random" and not os.environ.get("EXP_WINDOWS_FOR_ALL")) or order is None or order == (0, 0)) else os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(",")
+            forms = os.environ.get("EXP_GLOBAL_FORMS", "gather").split(",") if ((pattern == "random" and not os.environ.get("EXP_WINDOWS_FOR_ALL")) or order is None or order == (0, 0)) else os.environ.get("EXP_FORMS", "gather,tile0,tile2,tile3").split(",")
             run(h, f"power-law {pattern}, {name}", forms)
             del h
             torch.cuda.empty_cache()
