@@ -120,7 +120,7 @@ int spgpuTuningVariantsBuilt(void);
  *           AUTO takes this form by itself for the 8-byte types (since round 4) when the three-wavefront probe finds, in two of
  *           its three groups of rows: columns reaching over half the matrix' rows and more (the matrix is taken to be about
  *           square: no call says how long x is), ascending in every sampled row, rows about equally long (slots of the group
- *           <= 1.5 x its nonzeros) -- and the matrix has 4 Mi rows or more (the form wants a grid that fills the chip).
+ *           <= 1.5 x its nonzeros) -- and the matrix has 2 Mi rows or more (the form wants a grid that fills the chip).
  *           SPGPU_AUTO_SWEEP=0 keeps AUTO out of it.
  *
  * The hint applies to every later SpMV call on the handle, from any thread; SPGPU_X_STRIPS / SPGPU_X_TILE in the

@@ -1183,7 +1183,9 @@ static void launchTiled(hipStream_t stream, const SlabArgs<T>& a, int shape)
     }
 }
 
-constexpr int kAutoSweepRows = 4 * 1024 * 1024; /* AUTO: the SWEEP form wants a grid that fills the chip (8 192 rows per workgroup) */
+constexpr int kAutoSweepRows = 2 * 1024 * 1024; /* AUTO: the SWEEP form wants a grid that fills the chip (8 192 rows per workgroup); measured, scattered
+                                                  * fp64, 16 and 32 per row: 1 Mi rows 1.5 x SLOWER than the gathers (x fits the L2s), 2 Mi ... 16 Mi rows 0.61 ... 0.89 x their
+                                                  * time (profiles/r04_exp_sweep_rows.txt) */
 
 /* SWEEP: 32 rows per lane (16 for 16-byte elements), at most 2 048 workgroups.  8-byte elements add in the order of their
  * default kernel (whole-wave tail rows), the others in one phase. */

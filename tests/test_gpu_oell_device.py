@@ -426,7 +426,7 @@ def test_auto_form_settles_on_the_matrix(gpu, pattern, expect):
 def test_auto_takes_the_sweep_form_for_a_large_scattered_matrix(gpu, tuning):
     """AUTO and the SWEEP form (include/spgpu/tuning.h): the probe that looks at a matrix in the gather form again also finds out
     whether its columns reach over all of x, ascend inside the rows and the rows are about equally long; two of three samples
-    saying so select the SWEEP form for the 8-byte types on matrices of 4 Mi rows and more -- the same bits as the gather kernel
+    saying so select the SWEEP form for the 8-byte types on matrices of 2 Mi rows and more -- the same bits as the gather kernel
     and as the oracle in the default order.  The analysis call says the same; a 65 536-column window stays with the gathers; and
     SPGPU_AUTO_SWEEP=0 keeps AUTO out of it."""
     import torch
