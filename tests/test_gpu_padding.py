@@ -1,0 +1,93 @@
+"""GPU: what lies in the padding slots of the ELL / HELL arrays never reaches z.
+
+The reference's converters leave the slots beyond a row's length as they find them (ell.c:65-78, hell.c:93-96: only the row's
+entries are written) and its kernels never read them with rS given (`for j < rowSize`, hell_spmv_base_template.cuh:112-118).  In
+a long-lived process those slots hold whatever lived there before, so every kernel here that loads a slab column wholesale must
+select, not multiply.  Each slot (r, k) with k >= rowLength[r] gets a NaN coefficient and a random valid column; every form of
+the unordered SpMV and the ordered paths (first call, planned, SPGPU_PLAN=0) still give the oracle's bytes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+from test_gpu_plan import _call, _host, _matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def _poison_hell(cM, rP, lengths, offsets, hack, n):
+    """NaN / random columns into the padding slots of device HELL arrays (lengths, offsets: host)."""
+    import torch
+    rows = np.repeat(np.arange(n, dtype=np.int64), lengths)
+    ks = np.arange(int(lengths.sum()), dtype=np.int64) - np.repeat(np.cumsum(lengths) - lengths, lengths)
+    used = np.zeros(cM.numel(), bool)
+    used[offsets[rows // hack] + rows % hack + ks * hack] = True
+    padding = torch.from_numpy(~used).cuda()
+    count = int(padding.sum().item())
+    cM[padding] = float("nan")
+    rP[padding] = torch.randint(0, n, (count,), device="cuda", dtype=torch.int32)
+    torch.cuda.synchronize()
+    return count
+
+
+@pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
+@pytest.mark.parametrize("window,long_rows,aligned,hack", [(2048, 60, True, 32), (512, 40, False, 32), (0, 0, False, 64), (256, 100, False, 96)])
+def test_ordered_paths_never_use_padding(gpu, tuning, letter, window, long_rows, aligned, hack):
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 6 * 2048 + 300
+    h = _matrix(gpu, n, letter, window, long_rows, aligned, hack=hack, longest=900, near=500, seed=77)
+    lengths = h["rS"][:n].cpu().numpy().astype(np.int64)
+    offsets = h["hack_offsets"].cpu().numpy().astype(np.int64)
+    assert _poison_hell(h["cM"][:h["slots"]], h["rP"][:h["slots"]], lengths, offsets, hack, n) > 0
+    x, y = synth.values_for(letter, 31, n), synth.values_for(letter, 32, n)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    want = O.spmv_tail(_host(h, letter, n, hack), x, y, -0.5, 2.0, r_idx=h["rIdx"].cpu().numpy(), **O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP))
+    assert not np.isnan(want.view(np.float32 if letter in "SC" else np.float64)).any()
+    for plan in (1, 0):
+        tuning(SPGPU_PLAN=plan)
+        for call in range(5):
+            dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            torch.cuda.synchronize()
+            _call(gpu, letter, h, n, dz, dy, dx, -0.5, 2.0, hack)
+            torch.cuda.synchronize()
+            assert dz.cpu().numpy().tobytes() == want.tobytes(), (plan, call, capi.plan_counts(gpu))
+
+
+@pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
+@pytest.mark.parametrize("pattern", ["near", "band"])
+def test_unordered_forms_never_use_padding(gpu, letter, pattern):
+    """Rows as they come (ragged, so that every hack has padding): AUTO, gathers, strips, the LDS tile and the sweep."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n, hack = 5 * 2048 + 77, 32
+    real = {"S": "S", "D": "D", "C": "S", "Z": "D"}[letter]
+    lengths = np.minimum(synth.power_law_lengths(n, 10.0, 400, 5), 400)
+    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 300, real, seed=9)
+    if letter in "CZ":
+        vals_t = torch.complex(vals_t, torch.flip(vals_t, [0]))
+    h = formats.coo_to_ordered_hell_device(gpu, n, rows_t, cols_t, vals_t, letter, hack, 0, 0, order=False)
+    lens = h["rS"][:n].cpu().numpy().astype(np.int64)
+    offsets = h["hack_offsets"].cpu().numpy().astype(np.int64)
+    assert _poison_hell(h["cM"][:h["slots"]], h["rP"][:h["slots"]], lens, offsets, hack, n) > 0
+    x = synth.values_for(letter, 41, n)
+    dx = formats.to_device(x)
+    host = _host(h, letter, n, hack)
+    one, zero = capi.scalar(letter, 1.0), capi.scalar(letter, 0.0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    try:
+        for form in (capi.FORM_AUTO, capi.FORM_GATHER, capi.FORM_STRIPS, capi.FORM_XTILE, capi.FORM_SWEEP):
+            capi.spgpuSetSpmvForm(gpu, form)
+            for call in range(3):
+                dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+                torch.cuda.synchronize()
+                capi.hellspmv[letter](gpu, p(dz), None, one, p(h["cM"]), p(h["rP"]), hack, p(h["hack_offsets"]), p(h["rS"]), None, 10, n, p(dx), zero, 0)
+                torch.cuda.synchronize()
+                if form == capi.FORM_SWEEP and letter in "SZ":
+                    want = O.hell_spmv(host, x, None, 1.0, 0.0, phases=1)
+                else:
+                    want = O.default_spmv(host, x, None, 1.0, 0.0)
+                assert dz.cpu().numpy().tobytes() == want.tobytes(), (form, call)
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
