@@ -91,3 +91,55 @@ def test_unordered_forms_never_use_padding(gpu, letter, pattern):
                 assert dz.cpu().numpy().tobytes() == want.tobytes(), (form, call)
     finally:
         capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+
+
+@pytest.mark.parametrize("letter", ["S", "D", "C", "Z"])
+@pytest.mark.parametrize("n,cols_n,hack", [(4099, 4099, 32), (30011, 30051, 64), (1000, 987, 30), (257, 257, 96)])
+def test_diagonal_formats_never_use_slots_outside_the_matrix(gpu, letter, n, cols_n, hack):
+    """HDIA and DIA store whole diagonals: where a diagonal leaves the matrix (row + offset outside [0, cols), or a row beyond the last
+    in the final hack) the slot exists and is never used (hdia_spmv_base_template.cuh:111-118, dia_spmv_base_template.cuh:20-216).
+    Those slots get NaN; z is the oracle's, byte for byte, beta = 0 and beta != 0."""
+    import torch
+    from spgpu_amd import formats, synth
+    rng = np.random.default_rng(n + hack)
+    offsets = np.unique(np.concatenate(([0, 1, -1], rng.integers(-min(n, 2500) + 1, min(cols_n, 2500), 9))))
+    rows_l, cols_l = [], []
+    for off in offsets:
+        r = np.arange(n, dtype=np.int64)
+        c = r + off
+        keep = (c >= 0) & (c < cols_n)
+        rows_l.append(r[keep])
+        cols_l.append(c[keep])
+    rows, cols = np.concatenate(rows_l), np.concatenate(cols_l)
+    real = O.NP_DTYPE[{"S": "S", "C": "S", "D": "D", "Z": "D"}[letter]]
+    vals = rng.standard_normal(rows.size).astype(real)
+    if letter in "CZ":
+        vals = (vals + 1j * rng.standard_normal(rows.size).astype(real)).astype(O.NP_DTYPE[letter])
+    x, y = synth.values_for(letter, 51, cols_n), synth.values_for(letter, 52, n)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+
+    hdia = formats.coo_to_hdia(n, cols_n, rows, cols, vals, hack)
+    values, offs, hack_offsets = hdia["values"], hdia["offsets"], hdia["hack_offsets"]
+    poisoned = 0
+    for h in range(len(hack_offsets) - 1):
+        for pos in range(hack_offsets[h], hack_offsets[h + 1]):
+            r = h * hack + np.arange(hack, dtype=np.int64)
+            c = r + offs[pos]
+            outside = (r >= n) | (c < 0) | (c >= cols_n)
+            values[pos * hack + np.flatnonzero(outside)] = np.nan
+            poisoned += int(outside.sum())
+    assert poisoned > 0
+    dia = formats.coo_to_dia(n, cols_n, rows, cols, vals)
+    for d in range(dia["diags"]):
+        r = np.arange(dia["pitch"], dtype=np.int64)
+        c = r + dia["offsets"][d]
+        dia["values"][d * dia["pitch"] + np.flatnonzero((r >= n) | (c < 0) | (c >= cols_n))] = np.nan
+    for mat, oracle, host in ((formats.DeviceHdia(hdia), O.hdia_spmv, hdia), (formats.DeviceDia(dia), O.dia_spmv, dia)):
+        for alpha, beta in ((1.0, 0.0), (-0.75, 0.5)):
+            want = oracle(host, x, y if beta != 0 else None, alpha, beta)
+            assert not np.isnan(want.view(np.float32 if letter in "SC" else np.float64)).any()
+            dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+            torch.cuda.synchronize()
+            mat.spmv(gpu, dz, dy if beta != 0 else None, alpha, dx, beta)
+            torch.cuda.synchronize()
+            assert dz.cpu().numpy().tobytes() == want.tobytes(), (type(mat).__name__, alpha, beta)
