@@ -143,3 +143,34 @@ def test_diagonal_formats_never_use_slots_outside_the_matrix(gpu, letter, n, col
             mat.spmv(gpu, dz, dy if beta != 0 else None, alpha, dx, beta)
             torch.cuda.synchronize()
             assert dz.cpu().numpy().tobytes() == want.tobytes(), (type(mat).__name__, alpha, beta)
+
+
+@pytest.mark.parametrize("letter", ["S", "D"])
+@pytest.mark.parametrize("pattern,count", [("band", 16), ("near", 16), ("band", 8), ("near", 5)])
+def test_spmm_never_uses_padding(gpu, letter, pattern, count):
+    """spgpu?hellspmm on a ragged HELL whose padding slots hold NaN and random columns: band wavefronts (the sliding window of X rows),
+    the strip kernel's other wavefronts and the narrow right-hand-side counts all select, none multiplies."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n, hack = 5 * 2048 + 77, 32
+    lengths = np.minimum(synth.power_law_lengths(n, 10.0, 200, 6), 200)
+    lengths[: 2048] = 24                       # a stretch of even rows: band wavefronts (pattern "band") next to ragged ones
+    rows_t, cols_t, vals_t = synth.ragged_coo_on_device(lengths, n, pattern, 150, letter, seed=10)
+    h = formats.coo_to_ordered_hell_device(gpu, n, rows_t, cols_t, vals_t, letter, hack, 0, 0, order=False)
+    lens = h["rS"][:n].cpu().numpy().astype(np.int64)
+    offsets = h["hack_offsets"].cpu().numpy().astype(np.int64)
+    assert _poison_hell(h["cM"][:h["slots"]], h["rP"][:h["slots"]], lens, offsets, hack, n) > 0
+    X = synth.values_for(letter, 61, n * count).reshape(n, count)
+    Y = synth.values_for(letter, 62, n * count).reshape(n, count)
+    dX, dY = formats.to_device(X), formats.to_device(Y)
+    host = _host(h, letter, n, hack)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    for beta in (0.0, -0.5):
+        dZ = torch.full_like(dY, float("nan"))
+        torch.cuda.synchronize()
+        capi.hellspmm[letter](gpu, p(dZ), p(dY), capi.scalar(letter, 1.25), p(h["cM"]), p(h["rP"]), hack, p(h["hack_offsets"]), p(h["rS"]),
+                              None, 0, n, p(dX), capi.scalar(letter, beta), 0, count, count, count)
+        torch.cuda.synchronize()
+        want = O.hell_spmm(host, X, Y if beta != 0 else None, 1.25, beta)
+        assert not np.isnan(want).any()
+        assert dZ.cpu().numpy().tobytes() == want.tobytes(), beta
