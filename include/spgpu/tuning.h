@@ -29,6 +29,9 @@
  *   SPGPU_SPMM_VARIANT   SpMM kernel shape (0 = default, see csrc/hell_spmm.hip)
  *   SPGPU_L1_NT          Level-1 streams non-temporal: 1 always, 0 never, unset: vectors beyond the Infinity Cache
  *   SPGPU_L1_BLOCKS      grid cap of the Level-1 kernels (default 16384)
+ *   SPGPU_POISON_SCRATCH 1 (testing): device scratch the library allocates without having to initialise it -- the deep lists'
+ *                        sums, a plan's tables, the reduction scratch -- is filled with 0xFF bytes (NaN / -1) at allocation, so
+ *                        that a kernel reading such a word before writing it shows in the results
  *
  * Every setting computes the same values up to the summation order documented
  * per kernel; the defaults are the measured best on MI355X.

@@ -32,6 +32,8 @@ static void deepListFor(SpgpuPrivateHandle* h, hipStream_t stream)
         void* p = NULL;
         hipEvent_t idle = NULL;
         if (hipMalloc(&p, DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES + DEEP_PARTIAL_BYTES + DEEP_ITEM_SUM_BYTES) == hipSuccess) {
+            if (spgpuTuning()->poisonScratch)
+                (void)hipMemset((char*)p + DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES, 0xFF, DEEP_PARTIAL_BYTES + DEEP_ITEM_SUM_BYTES);
             if (hipMemset(p, 0, DEEP_HEAD_BYTES + DEEP_ENTRY_BYTES + DEEP_ITEM_ENTRY_BYTES) == hipSuccess &&
                 hipEventCreateWithFlags(&idle, hipEventDisableTiming) == hipSuccess) {
                 h->deepScratch[h->deepStreams] = p;
@@ -95,6 +97,8 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
         err = hipStreamCreate(&h->pub.defaultStream);
     if (err == hipSuccess)
         err = hipMalloc(&h->reduceScratch, SPGPU_REDUCE_SCRATCH_BYTES);
+    if (err == hipSuccess && spgpuTuning()->poisonScratch)
+        err = hipMemset(h->reduceScratch, 0xFF, SPGPU_REDUCE_SCRATCH_BYTES);
     if (err == hipSuccess)
         err = hipHostMalloc(&h->reduceHost, SPGPU_REDUCE_SCRATCH_BYTES, hipHostMallocDefault);
     if (err == hipSuccess)
@@ -473,6 +477,7 @@ void spgpuTuningReload(void)
     t.xStrips = envInt("SPGPU_X_STRIPS", -1);
     t.xTile = envInt("SPGPU_X_TILE", -1);
     t.autoSweep = envInt("SPGPU_AUTO_SWEEP", 1);
+    t.poisonScratch = envInt("SPGPU_POISON_SCRATCH", 0);
     t.slide = envInt("SPGPU_SLIDE", 0);
     t.xTileShape = envInt("SPGPU_X_TILE_SHAPE", 0);
     t.deepSplit = envInt("SPGPU_DEEP_SPLIT", -1);

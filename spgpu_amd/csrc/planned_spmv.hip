@@ -184,6 +184,8 @@ static void startPlan(spgpuHandle_t handle, SpgpuSpmvPlan* plan, hipStream_t str
         plan->state = SPGPU_PLAN_EMPTY;
         return;
     }
+    if (spgpuTuning()->poisonScratch) /* testing: the analysis must write every word a launch reads */
+        (void)hipMemsetAsync(device, 0xFF, blockBytes + countBytes + (size_t)subs * sizeof(int), stream);
     plan->device = device;
     plan->blocks = blocks;
     plan->deep = 0;

@@ -203,6 +203,9 @@ typedef struct SpgpuTuning {
     int xStrips;     /* -1: by feedback */
     int xTile;       /* -1: by the handle's hint */
     int autoSweep;   /* 1: AUTO may pick the SWEEP form (SPGPU_AUTO_SWEEP=0: never) */
+    int poisonScratch; /* 0; SPGPU_POISON_SCRATCH=1 (testing): device scratch the library allocates and does not have to initialise -- the deep lists'
+                        * sums, a plan's tables, the reduction scratch -- is filled with 0xFF bytes (NaN / -1) when it is allocated: a kernel that
+                        * read such a word before writing it would show */
     int slide;       /* 0; lab builds: 1 = the moving x tile of slide_spmv.hip.h for 8-byte elements (experiment) */
     int xTileShape;  /* 0 */
     int deepSplit;   /* -1: when rIdx is given */
