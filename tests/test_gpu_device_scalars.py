@@ -137,6 +137,7 @@ def test_cg_iteration_replays_from_one_graph(gpu):
     RR, RRN, PAP, AL, NAL, BE, ONE = (s[i:] for i in range(7))
     side = torch.cuda.Stream()
     capi.spgpuSetStream(gpu, C.c_void_p(side.cuda_stream))
+    torch.cuda.synchronize()   # the vectors and scalars above were written on torch's stream; `side` does not wait for it by itself
     try:
         with torch.cuda.stream(side):
             capi.dot_device["D"](gpu, _p(RR), n, _p(rvec), _p(rvec))
@@ -156,6 +157,7 @@ def test_cg_iteration_replays_from_one_graph(gpu):
             iteration()                      # warm-up outside the capture (module load), then start over
         side.synchronize()
         x, rvec, p, ap = fresh()
+        torch.cuda.synchronize()
         with torch.cuda.stream(side):
             capi.dot_device["D"](gpu, _p(RR), n, _p(rvec), _p(rvec))
         side.synchronize()

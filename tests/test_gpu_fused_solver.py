@@ -156,6 +156,7 @@ def test_fused_cg_iteration_equals_eager(gpu):
     s = torch.zeros(3, dtype=torch.float64, device="cuda:0")      # |r|^2 (two cells, alternating), p.Ap
     side = torch.cuda.Stream()
     capi.spgpuSetStream(gpu, C.c_void_p(side.cuda_stream))
+    torch.cuda.synchronize()   # the vectors above were written on torch's stream; `side` does not wait for it by itself
 
     def iteration(rr_old, rr_new):
         capi.hellspmv_dot_device["D"](gpu, _p(s[2:]), None, _p(ap), None, 1.0, _p(mat.cM), _p(mat.rP), 32,
@@ -169,6 +170,7 @@ def test_fused_cg_iteration_equals_eager(gpu):
             iteration(s[0:], s[1:])          # warm-up outside the capture (module load), then start over
         side.synchronize()
         x.zero_(), rvec.copy_(b), p.copy_(b)
+        torch.cuda.synchronize()
         with torch.cuda.stream(side):
             capi.dot_device["D"](gpu, _p(s), n, _p(rvec), _p(rvec))
         side.synchronize()

@@ -540,6 +540,7 @@ def test_deep_list_in_a_replayed_graph(gpu):
                                       _dp(h["rIdx"]), 14, n, _dp(dx), 0.0, 0)
     side = torch.cuda.Stream()
     capi.spgpuSetStream(gpu, C.c_void_p(side.cuda_stream))
+    torch.cuda.synchronize()   # dz was zeroed on torch's stream; `side` does not wait for it by itself
     try:
         with torch.cuda.stream(side):
             call()                               # warm-up outside the capture (the stream's list exists since spgpuSetStream)

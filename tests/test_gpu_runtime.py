@@ -40,6 +40,7 @@ def test_spmv_and_axpby_capture_into_a_hip_graph(gpu):
 
     side = torch.cuda.Stream()
     capi.spgpuSetStream(gpu, C.c_void_p(side.cuda_stream))
+    torch.cuda.synchronize()   # the buffers were set up on torch's stream; `side` does not wait for it by itself
     with torch.cuda.stream(side):
         step()
     side.synchronize()

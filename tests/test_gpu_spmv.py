@@ -240,6 +240,7 @@ def test_handle_and_streams(gpu):
     capi.spgpuSetStream(gpu, C.c_void_p(ts.cuda_stream))
     a = torch.arange(1000, dtype=torch.float64, device="cuda:0")
     z = torch.empty_like(a)
+    torch.cuda.synchronize()   # `a` was filled on torch's stream; `ts` does not wait for it by itself
     with torch.cuda.stream(ts):
         capi.axpby["D"](gpu, C.c_void_p(z.data_ptr()), 1000, 0.0, None, 2.0, C.c_void_p(a.data_ptr()))
     ts.synchronize()
