@@ -634,8 +634,10 @@ def run_spmv(args, rank, world):
         roofline=dict(bound="hbm", achieved=round(alg / per_launch * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=round(alg / per_launch * 1e-9 / HBM_PEAK_GBS, 4),
                       traffic=committed_traffic(h["rows"], args.nnz_per_row, args.pattern),
-                      kernel=f"slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, prefetch after gathers, tail> in the form "
-                             f"spgpuGetLastSpmvForm reports: {headline_form}", algorithmic_bytes_per_launch=alg,
+                      kernel=("sweepSpmvKernel<double, 2 rows x 16 packs per lane, HELL, the default kernel's tail order>: the form "
+                              "spgpuGetLastSpmvForm reports: sweep" if headline_form == "sweep" else
+                              "slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, prefetch after gathers, tail> in the form "
+                              f"spgpuGetLastSpmvForm reports: {headline_form}"), algorithmic_bytes_per_launch=alg,
                       kernel_ms=round(per_launch * 1e3, 5), kernel_ms_blocks=spread(blocks)),
         device=device,
     )
