@@ -329,13 +329,24 @@ def bench_powerlaw(args, handle, stream, dev, rows):
                 out[f"{pattern}_vendor_context"] = repr(error)
         # "sorted_aligned": spgpuOellOrderAlignedDevice -- every window of the order is one 2 048-row workgroup (include/spgpu/ell_conv.h)
         # "sorted_global": the reference's own order -- ellToOell, ONE sort of all rows by length (ell.c:85-202, hellPerf.cpp:333-378)
-        for name, ordered in ({"band": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True)),
-                               "near": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True)),
+        # "*_frozen": the same arrays after spgpuHellSpmvFreeze (include/spgpu/tuning.h: the caller promises that the index arrays
+        # stay as they are; the library keeps a 16-bit copy of the column indices with the matrix' plan) -- the same ABI call,
+        # 10 instead of 12 bytes per nonzero streamed; `frac` is still ALGORITHMIC bytes (12 per nonzero) / time / peak
+        for name, ordered in ({"band": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True), ("sorted_aligned_frozen", True)),
+                               "near": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True), ("sorted_aligned_frozen", True)),
                                "random": (("plain", False), ("sorted", True))}[pattern]):
             t0 = time.perf_counter()
             window, long_rows = (0, 0) if name == "sorted_global" else (2048, 256)
-            h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, window, long_rows, order=ordered, aligned=name.endswith("aligned"))
+            frozen = name.endswith("_frozen")
+            h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, window, long_rows, order=ordered, aligned="aligned" in name)
             build_s = time.perf_counter() - t0
+            freeze = lambda a: capi.spgpuHellSpmvFreeze(handle, capi.TYPE_CODE[letter], a["cM"], a["rP"], 32, a["hack_offsets"], a["rS"], a["rIdx"], rows, 0)
+            if frozen:
+                t0 = time.perf_counter()
+                said = freeze({k: p(h[k]) for k in ("cM", "rP", "hack_offsets", "rS", "rIdx")})
+                torch.cuda.synchronize()
+                freeze_s, frozen_bytes = time.perf_counter() - t0, capi.spgpuSpmvFrozenBytes(handle)
+                assert said == capi.SPGPU_SUCCESS, said
             # form AUTO throughout: through rIdx the tile form falls back to gathers column by column, and on scattered
             # columns it runs within 1 % of the plain gather form (tools/exp_tile.py, ragged0 vs raggedg)
             capi.spgpuSetSpmvForm(handle, capi.FORM_AUTO)
@@ -352,11 +363,15 @@ def bench_powerlaw(args, handle, stream, dev, rows):
                     own = OwnAllocations(dict(cM=h["cM"], rP=h["rP"], hack_offsets=h["hack_offsets"], rS=h["rS"], rIdx=h["rIdx"], x=x, z=z))
                     try:
                         torch.cuda.synchronize()
+                        if frozen:
+                            assert freeze(own) == capi.SPGPU_SUCCESS
                         placed = lambda own=own: capi.hellspmv[letter](handle, own["z"], None, C.c_double(1.0), own["cM"], own["rP"], 32, own["hack_offsets"],
                                                                        own["rS"], own["rIdx"], 32, rows, own["x"], C.c_double(0.0), 0)
                         placements.append(timed_blocks(stream, placed))
                     finally:
                         torch.cuda.synchronize()
+                        if frozen:
+                            capi.spgpuSpmvThaw(handle, own["rP"])
                         own.free()
                 t = sorted(sorted(blocks)[len(blocks) // 2] for blocks in placements)[len(placements) // 2] * 1e-3
             z.zero_()
@@ -381,6 +396,12 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             if ordered:
                 entry = out[f"{pattern}_{name}"]
                 entry["plan_counts_uses_builds_stales"] = list(capi.plan_counts(handle))
+            if frozen:
+                entry = out[f"{pattern}_{name}"]
+                entry["freeze_ms"] = round(freeze_s * 1e3, 1)
+                entry["frozen_copy_GB"] = round(frozen_bytes * 1e-9, 3)
+                entry["streamed_bytes_per_nnz"] = elem + 2
+                capi.spgpuSpmvThaw(handle, p(h["rP"]))
             del h
             torch.cuda.empty_cache()
         del coo
@@ -664,12 +685,16 @@ def run_spmv(args, rank, world):
                     own = OwnAllocations(dict(cM=h["cM"], rP=h["rP"], hack_offsets=h["hack_offsets"], rS=h["rS"], x=x, z=z))
                     try:
                         torch.cuda.synchronize()
+                        if frozen:
+                            assert freeze(own) == capi.SPGPU_SUCCESS
                         placed = lambda own=own: capi.hellspmv["D"](handle, own["z"], None, C.c_double(1.0), own["cM"], own["rP"], h["hack_size"],
                                                                     own["hack_offsets"], own["rS"], None, args.nnz_per_row, h["rows"], own["x"],
                                                                     C.c_double(0.0), 0)
                         moved.append([round(v, 4) for v in timed_blocks(stream, placed)])
                     finally:
                         torch.cuda.synchronize()
+                        if frozen:
+                            capi.spgpuSpmvThaw(handle, own["rP"])
                         own.free()
                 every = [v for blocks in moved for v in blocks]
                 out["roofline"]["placements_kernel_ms"] = moved
@@ -752,14 +777,17 @@ def run_spmv(args, rank, world):
                 torch.cuda.empty_cache()
             out["configs"] = configs
             pl = configs.get("powerlaw_fp64", {})
-            target = {name: {key: pl[name][key] for key in ("ms", "frac", "frac_spread", "ms_spread", "slots_per_nnz", "parity") if key in pl[name]}
-                      for name in ("band_sorted_aligned", "band_sorted", "near_sorted_aligned", "near_sorted", "band_sorted_global", "band_plain", "near_plain")
+            target = {name: {key: pl[name][key] for key in ("ms", "frac", "frac_spread", "ms_spread", "slots_per_nnz", "streamed_bytes_per_nnz", "parity") if key in pl[name]}
+                      for name in ("band_sorted_aligned", "band_sorted_aligned_frozen", "band_sorted", "near_sorted_aligned", "near_sorted_aligned_frozen",
+                                   "near_sorted", "band_sorted_global", "band_plain", "near_plain")
                       if isinstance(pl.get(name), dict)}
             target["what"] = ("north_star target: spgpuDhellspmv, fp64, 10 M rows, power-law lengths (mean 32, max 2048), rows ordered "
                               "on the device (windows of 2048, rows > 256 set aside) and run through rIdx; *_aligned: the order whose windows "
                               "coincide with the kernel's 2048-row workgroups (spgpuOellOrderAlignedDevice); *_global: the reference's own order, "
-                              "one sort of all rows (ellToOell, ell.c:85-202); *_plain: the rows as they come, no rIdx; frac = algorithmic bytes / "
-                              "time / 8 TB/s, time = median over placements of the arrays (ms_spread / frac_spread: every timed block); bar 0.70")
+                              "one sort of all rows (ellToOell, ell.c:85-202); *_plain: the rows as they come, no rIdx; *_frozen: the same arrays and the same "
+                              "spgpuDhellspmv call after spgpuHellSpmvFreeze (the caller's promise that the index arrays stay as they are: the library "
+                              "streams its 16-bit copy of the column indices, 10 instead of 12 bytes per nonzero; bit-identical results); frac = "
+                              "algorithmic bytes (12 per nonzero, frozen or not) / time / 8 TB/s, time = median over placements of the arrays (ms_spread / frac_spread: every timed block); bar 0.70")
             out["config"]["north_star_target"] = target
             out["target"] = target
             if world == 1:

@@ -89,6 +89,31 @@ int spgpuHellSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM,
 int spgpuEllSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int cMPitch, int rPPitch, const int* rS, const int* rIdx,
                         int maxNnzPerRow, int rows, int baseIndex);
 
+/*
+ * FROZEN matrices (no counterpart in the reference).  An iterative solver multiplies by one matrix thousands of times
+ * (hellPerf.cpp:301-313 is that loop); its index arrays never change in between.  A caller who can PROMISE that -- rP, rS,
+ * hackOffsets and rIdx of this matrix stay byte for byte as they are until spgpuSpmvThaw (cM may change at any time: the
+ * coefficients are always read from the caller's array) -- lets the library keep what it derives from them: spgpu?SpmvFreeze
+ * does what spgpu?SpmvPrepare does and then stores, with the plan, the column indices of the matrix as 16-bit offsets from
+ * the first column each block of 1 024 / 2 048 ordered rows reaches (2 bytes per slot of rP; 0xFFFF where a column lies out of
+ * that reach: such entries are still read from rP).  Later spgpu?hellspmv / spgpu?ellspmv calls on these arrays -- the same ABI
+ * calls, nothing else changes for the caller -- stream 2 bytes of index per stored entry instead of 4: 10 instead of 12 bytes per
+ * nonzero in fp64.  Same columns, same x, same order of additions: the bits of z are those of the unfrozen call.
+ *   SPGPU_SUCCESS      frozen (or already so);
+ *   SPGPU_UNSUPPORTED  calls of this kind have no plan or no packed form (no rIdx, complex fp64, the gather form, SPGPU_PLAN=0)
+ *                      or there was no memory for the copy: nothing is frozen, nothing wrong.
+ * Breaking the promise gives wrong results for the entries that changed (the library cannot see it: checking would mean
+ * reading rP, which is what the copy saves) -- except that a matrix whose row LENGTHS changed is noticed like any stale plan.
+ * A frozen plan ends with spgpuSpmvThaw(handle, rP), when it is the least recently used of 8 matrices, or with the handle.
+ * spgpuSpmvFrozenBytes: device memory the handle's frozen plans hold.
+ */
+int spgpuHellSpmvFreeze(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,
+                        const int* rIdx, int rows, int baseIndex);
+int spgpuEllSpmvFreeze(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int cMPitch, int rPPitch, const int* rS, const int* rIdx,
+                       int maxNnzPerRow, int rows, int baseIndex);
+int spgpuSpmvThaw(spgpuHandle_t handle, const int* rP);
+long long spgpuSpmvFrozenBytes(spgpuHandle_t handle);
+
 void spgpuTuningReload(void);
 /* 1 if the library was built with -DSPGPU_TUNING_VARIANTS: the non-default kernel shapes (SPGPU_SPMV_VARIANT, SPGPU_X_TILE_SHAPE,
  * SPGPU_RAGGED_SHAPE, SPGPU_RAGGED=0) exist only in such a build; the product build carries the defaults and ignores those knobs. */

@@ -260,6 +260,10 @@ spgpuDeepListFallbacks = _decl("spgpuDeepListFallbacks", i32, [Handle])
 spgpuDeepListsRecycled = _decl("spgpuDeepListsRecycled", i32, [Handle])
 spgpuSpmvPlanCounts = _decl("spgpuSpmvPlanCounts", None, [Handle, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)])
 spgpuHellSpmvPrepare = _decl("spgpuHellSpmvPrepare", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, ptr, i32, i32])
+spgpuHellSpmvFreeze = _decl("spgpuHellSpmvFreeze", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, ptr, i32, i32])
+spgpuEllSpmvFreeze = _decl("spgpuEllSpmvFreeze", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, ptr, i32, i32, i32])
+spgpuSpmvThaw = _decl("spgpuSpmvThaw", i32, [Handle, ptr])
+spgpuSpmvFrozenBytes = _decl("spgpuSpmvFrozenBytes", C.c_longlong, [Handle])
 spgpuEllSpmvPrepare = _decl("spgpuEllSpmvPrepare", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, ptr, i32, i32, i32])
 
 

@@ -173,6 +173,8 @@ void spgpuDestroy(spgpuHandle_t pHandle)
         for (int i = 0; i < SPGPU_PLANS; ++i) {
             if (h->plans[i].device)
                 hipFree(h->plans[i].device);
+            if (h->plans[i].packed)
+                hipFree(h->plans[i].packed);
             if (h->plans[i].built)
                 hipEventDestroy(h->plans[i].built);
         }
@@ -356,7 +358,10 @@ void spgpuPlanUnlock(spgpuHandle_t pHandle)
 void spgpuPlanRetire(spgpuHandle_t pHandle, SpgpuSpmvPlan* plan)
 {
     SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
-    if (plan->device) {
+    void** const buffers[2] = {&plan->device, &plan->packed};
+    for (int b = 0; b < 2; ++b) {
+        if (!*buffers[b])
+            continue;
         if (h->planGraves == SPGPU_PLAN_GRAVES) {
             /* kernels in flight on any stream may still read a retired plan: wait for the device before the buffers go
              * (once per SPGPU_PLAN_GRAVES retirements; never while a stream of the process captures -- see launchPlanned) */
@@ -365,8 +370,8 @@ void spgpuPlanRetire(spgpuHandle_t pHandle, SpgpuSpmvPlan* plan)
                 hipFree(h->planGraveyard[i]);
             h->planGraves = 0;
         }
-        h->planGraveyard[h->planGraves++] = plan->device;
-        plan->device = NULL;
+        h->planGraveyard[h->planGraves++] = *buffers[b];
+        *buffers[b] = NULL;
     }
     plan->state = SPGPU_PLAN_EMPTY;
     plan->uses = 0;
@@ -410,6 +415,7 @@ SpgpuSpmvPlan* spgpuPlanRecord(spgpuHandle_t pHandle, const SpgpuSpmvPlan* key)
     oldest->pinned = pinned;
     oldest->built = built;
     oldest->device = NULL;
+    oldest->packed = NULL;
     oldest->state = givenUp ? SPGPU_PLAN_GIVEN_UP : SPGPU_PLAN_EMPTY;
     oldest->stales = 0;
     oldest->uses = 0;
@@ -427,6 +433,39 @@ void spgpuSpmvPlanCounts(spgpuHandle_t pHandle, int* uses, int* builds, int* sta
     if (builds) *builds = h->planBuilds;
     if (stales) *stales = h->planStales;
     pthread_mutex_unlock(&h->formLock);
+}
+
+/* spgpu?SpmvFreeze's counterpart (include/spgpu/tuning.h): the plans of the matrix with this index array lose their 16-bit copies
+ * -- retired whole, the next SpMV analyses the matrix again. */
+int spgpuSpmvThaw(spgpuHandle_t pHandle, const int* rP)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    int thawed = 0;
+    if (!h || !h->plans || !rP)
+        return SPGPU_UNSPECIFIED;
+    pthread_mutex_lock(&h->formLock);
+    for (int i = 0; i < SPGPU_PLANS; ++i) {
+        SpgpuSpmvPlan* p = &h->plans[i];
+        if (p->rows > 0 && p->rP == (const void*)rP && p->packed) {
+            spgpuPlanRetire(pHandle, p);
+            thawed += 1;
+        }
+    }
+    pthread_mutex_unlock(&h->formLock);
+    return thawed ? SPGPU_SUCCESS : SPGPU_UNSUPPORTED;
+}
+
+long long spgpuSpmvFrozenBytes(spgpuHandle_t pHandle)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    long long bytes = 0;
+    if (!h || !h->plans)
+        return 0;
+    pthread_mutex_lock(&h->formLock);
+    for (int i = 0; i < SPGPU_PLANS; ++i)
+        bytes += h->plans[i].packed ? h->plans[i].packedBytes : 0;
+    pthread_mutex_unlock(&h->formLock);
+    return bytes;
 }
 
 /* ---- per-handle kernel-form hint (include/spgpu/tuning.h) ---- */

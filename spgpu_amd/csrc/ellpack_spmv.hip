@@ -1249,6 +1249,7 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
     /* prepared != NULL (spgpu?SpmvPrepare, include/spgpu/tuning.h): nothing is multiplied -- the choices a first SpMV would leave
      * to later calls are made now and waited for: the ordered matrix' workgroup shape (the probe) and its plan.
      * *prepared: 1 = the next SpMV on these arrays runs from a plan; 0 = this kind of call has none. */
+    const bool freeze = prepared && *prepared == 2; /* spgpu?SpmvFreeze: the plan also gets its 16-bit copy of the indices */
     if (prepared)
         *prepared = 0;
     if (in.rows <= 0)
@@ -1419,10 +1420,10 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
             shape = 0;
         if (prepared) {
             if (!tiledForm || shape == 0 || shape == 4 || shape == 5)
-                *prepared = launchPlanned<T, IS_HELL>(handle, stream, a, shape, tiledForm, false, true) ? 1 : 0;
+                *prepared = launchPlanned<T, IS_HELL>(handle, stream, a, shape, tiledForm, false, freeze ? 2 : 1) ? 1 : 0;
             return;
         }
-        if ((!tiledForm || shape == 0 || shape == 4 || shape == 5) && launchPlanned<T, IS_HELL>(handle, stream, a, shape, tiledForm, noDeepList, false))
+        if ((!tiledForm || shape == 0 || shape == 4 || shape == 5) && launchPlanned<T, IS_HELL>(handle, stream, a, shape, tiledForm, noDeepList, 0))
             return;
         const bool deepKernels = launchRagged<T, WIDE, IS_HELL, true>(stream, a, shape, form != SPGPU_SPMV_FORM_GATHER);
         if (deepPossible && deepKernels)
@@ -1644,7 +1645,7 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
 /* spgpu?SpmvPrepare (include/spgpu/tuning.h): the dispatch of an SpMV on these arrays, with nothing multiplied */
 template <typename T, bool IS_HELL>
 static int prepareSpmv(spgpuHandle_t handle, const void* cM, const int* rP, int hackSize, const int* hackOffsets, long long valStride, long long idxStride,
-                       const int* rS, const int* rIdx, int maxNnz, int rows, int baseIndex)
+                       const int* rS, const int* rIdx, int maxNnz, int rows, int baseIndex, bool freeze)
 {
     SlabArgs<T> a{};
     a.cM = static_cast<const T*>(cM);
@@ -1658,22 +1659,22 @@ static int prepareSpmv(spgpuHandle_t handle, const void* cM, const int* rP, int 
     a.maxNnz = maxNnz;
     a.valStride = valStride;
     a.idxStride = idxStride;
-    int prepared = 0;
+    int prepared = freeze ? 2 : 0; /* in: what is asked for; out: 1 = done */
     launchSlabFamily<T, IS_HELL>(handle, a, &prepared);
     return prepared ? SPGPU_SUCCESS : SPGPU_UNSUPPORTED;
 }
 
 template <bool IS_HELL>
 static int prepareSpmvOfType(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, long long valStride,
-                             long long idxStride, const int* rS, const int* rIdx, int maxNnz, int rows, int baseIndex)
+                             long long idxStride, const int* rS, const int* rIdx, int maxNnz, int rows, int baseIndex, bool freeze = false)
 {
     if (!handle || !rP || !cM || rows < 0)
         return SPGPU_UNSPECIFIED;
     switch (type) {
-    case SPGPU_TYPE_FLOAT: return prepareSpmv<float, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex);
-    case SPGPU_TYPE_DOUBLE: return prepareSpmv<double, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex);
-    case SPGPU_TYPE_COMPLEX_FLOAT: return prepareSpmv<cfloat, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex);
-    case SPGPU_TYPE_COMPLEX_DOUBLE: return prepareSpmv<cdouble, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex);
+    case SPGPU_TYPE_FLOAT: return prepareSpmv<float, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex, freeze);
+    case SPGPU_TYPE_DOUBLE: return prepareSpmv<double, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex, freeze);
+    case SPGPU_TYPE_COMPLEX_FLOAT: return prepareSpmv<cfloat, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex, freeze);
+    case SPGPU_TYPE_COMPLEX_DOUBLE: return prepareSpmv<cdouble, IS_HELL>(handle, cM, rP, hackSize, hackOffsets, valStride, idxStride, rS, rIdx, maxNnz, rows, baseIndex, freeze);
     default: return SPGPU_UNSPECIFIED;
     }
 }
@@ -1804,6 +1805,20 @@ int spgpuEllSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, 
                         int maxNnzPerRow, int rows, int baseIndex)
 {
     return spgpu::prepareSpmvOfType<false>(handle, type, cM, rP, 0, nullptr, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, baseIndex);
+}
+
+int spgpuHellSpmvFreeze(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,
+                        const int* rIdx, int rows, int baseIndex)
+{
+    if (!hackOffsets || !rS || hackSize <= 0)
+        return SPGPU_UNSPECIFIED;
+    return spgpu::prepareSpmvOfType<true>(handle, type, cM, rP, hackSize, hackOffsets, hackSize, hackSize, rS, rIdx, 0, rows, baseIndex, true);
+}
+
+int spgpuEllSpmvFreeze(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int cMPitch, int rPPitch, const int* rS, const int* rIdx,
+                       int maxNnzPerRow, int rows, int baseIndex)
+{
+    return spgpu::prepareSpmvOfType<false>(handle, type, cM, rP, 0, nullptr, cMPitch, rPPitch, rS, rIdx, maxNnzPerRow, rows, baseIndex, true);
 }
 
 int spgpuEllSpmvForm(spgpuHandle_t handle, spgpuType_t type, const int* rP, int rPPitch, const int* rS, int maxNnzPerRow, int rows,

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void planBlocksKernel(const int* __restrict__ 
         out.probed = all.rows;
         out.deepMask = (unsigned long long)maskWords[0] | ((unsigned long long)maskWords[1] << 32);
         out.firstDeep = 0;
-        out.reserved = 0;
+        out.packBase = 0;
         blocks[blockIdx.x] = out;
         counts[blockIdx.x] = __popcll(out.deepMask);
     }
@@ -157,7 +157,132 @@ __global__ __launch_bounds__(1024) void planListKernel(SpgpuPlanBlock* blocks, c
         deepCountHost[0] = carry;
 }
 
+/* ---- freeze: the 16-bit copy of the column indices (spgpu?SpmvFreeze, include/spgpu/tuning.h) -------------------------------- */
+
+/* HELL does not say how many slots its arrays have (hackOffsets has no trailing total, hell.c:64,75): the last hack's offset plus
+ * hackSize times its longest row.  One wavefront; the answer (< 2^32: slot numbers are what hackOffsets, an int array, can name)
+ * goes to a pinned word. */
+__global__ __launch_bounds__(kWave) void planSlotsKernel(const int* __restrict__ rS, const int* __restrict__ hackOffsets, int hackSize, int rows,
+                                                        int* slotsHost)
+{
+    const int lastHack = (rows - 1) / hackSize;
+    int longest = 0;
+    for (long long r = (long long)lastHack * hackSize + threadIdx.x; r < rows; r += kWave)
+        longest = rS[r] > longest ? rS[r] : longest;
+    longest = waveReduce(longest, MaxOf{});
+    if (threadIdx.x == 0)
+        slotsHost[0] = (int)((unsigned)hackOffsets[lastHack] + (unsigned)hackSize * (unsigned)longest);
+}
+
+/* A workgroup per block of the plan: where the block's 16-bit words count from (packBase: the block's lowest column when all
+ * of them are within 16 bits of it -- the x tile then starts there too -- else 32 767 below the middle), and the words of every
+ * row the block walks itself.  0xFFFF = "ask rP": a column below the base, 65 535 or more above it, or negative (a slot the
+ * kernels skip).  Rows of deep sub-groups are left out: their workgroups read rP. */
+template <bool IS_HELL, int SUBS>
+__global__ __launch_bounds__(256) void planPackKernel(const int* __restrict__ rP, const int* __restrict__ rS, const int* __restrict__ hackOffsets,
+                                                     int hackSize, long long idxStride, int maxNnz, int rows, int baseIndex,
+                                                     SpgpuPlanBlock* blocks, unsigned short* __restrict__ packed)
+{
+    constexpr int BLOCK = 256, ROWS = SUBS * 32, RPT = ROWS / BLOCK;
+    const SpgpuPlanBlock record = blocks[blockIdx.x]; /* (workgroup-uniform) */
+    int packBase = 0;
+    if (record.probed > 0) {
+        const long long span = (long long)record.highest - record.lowest;
+        if (span <= 0xFFFE) {
+            packBase = record.lowest;
+        } else {
+            long long start = (long long)record.middle - 0x7FFF;
+            start = start < record.lowest ? record.lowest : start;
+            start = start > (long long)record.highest - 0xFFFE ? (long long)record.highest - 0xFFFE : start;
+            packBase = (int)start;
+        }
+    }
+    if (threadIdx.x == 0)
+        blocks[blockIdx.x].packBase = packBase;
+    const long long blockRow0 = (long long)blockIdx.x * ROWS;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int i = threadIdx.x + j * BLOCK;
+        const long long r = blockRow0 + i;
+        if (r >= rows || ((record.deepMask >> (i >> 5)) & 1ull) != 0ull)
+            continue;
+        const int len = rS ? rS[r] : maxNnz;
+        long long at;
+        if constexpr (IS_HELL) {
+            const unsigned u = (unsigned)r, hs = (unsigned)hackSize;
+            at = (long long)((unsigned)hackOffsets[u / hs] + u % hs);
+        } else {
+            at = r;
+        }
+        for (int k = 0; k < len; ++k, at += idxStride) {
+            const int col = rP[at] - baseIndex;
+            const long long off = (long long)col - packBase;
+            packed[at] = col >= 0 && off >= 0 && off < 0xFFFF ? (unsigned short)off : (unsigned short)0xFFFF;
+        }
+    }
+}
+
+/* Lock held, plan READY.  Builds the plan's 16-bit index copy on `stream` and waits for it.  False: no memory, or a launch failed
+ * (the plan stays as it is, unfrozen). */
+template <bool IS_HELL>
+static bool packPlan(SpgpuSpmvPlan* plan, spgpuHandle_t handle, hipStream_t stream)
+{
+    const int* rP = static_cast<const int*>(plan->rP);
+    const int* rS = static_cast<const int*>(plan->rS);
+    const int* hackOffsets = static_cast<const int*>(plan->hackOffsets);
+    long long slots = 0;
+    if constexpr (IS_HELL) {
+        plan->pinned[2] = 0;
+        hipLaunchKernelGGL(planSlotsKernel, dim3(1), dim3(kWave), 0, stream, rS, hackOffsets, plan->hackSize, plan->rows, plan->pinned + 2);
+        if (hipStreamSynchronize(stream) != hipSuccess)
+            return false;
+        slots = (long long)(unsigned)((volatile int*)plan->pinned)[2];
+    } else {
+        slots = plan->idxStride * (long long)plan->maxNnz;
+    }
+    if (slots <= 0)
+        return false;
+    const size_t bytes = ((size_t)slots * sizeof(unsigned short) + 255) / 256 * 256; /* (a lane's last pack may reach past the last real slot's word) */
+    void* packed = nullptr;
+    int previous = 0;
+    (void)hipGetDevice(&previous);
+    (void)hipSetDevice(handle->device);
+    const hipError_t allocated = hipMalloc(&packed, bytes);
+    (void)hipSetDevice(previous);
+    if (allocated != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (spgpuTuning()->poisonScratch) /* testing: no word is read that the pack kernel has not written */
+        (void)hipMemsetAsync(packed, 0xA5, bytes, stream);
+    SpgpuPlanBlock* records = static_cast<SpgpuPlanBlock*>(plan->device);
+    unsigned short* words = static_cast<unsigned short*>(packed);
+    if (plan->subs == 64)
+        hipLaunchKernelGGL((planPackKernel<IS_HELL, 64>), dim3((unsigned)plan->blocks), dim3(256), 0, stream, rP, rS, hackOffsets, plan->hackSize,
+                           plan->idxStride, plan->maxNnz, plan->rows, plan->baseIndex, records, words);
+    else
+        hipLaunchKernelGGL((planPackKernel<IS_HELL, 32>), dim3((unsigned)plan->blocks), dim3(256), 0, stream, rP, rS, hackOffsets, plan->hackSize,
+                           plan->idxStride, plan->maxNnz, plan->rows, plan->baseIndex, records, words);
+    if (hipStreamSynchronize(stream) != hipSuccess) {
+        (void)hipFree(packed);
+        return false;
+    }
+    plan->packed = packed;
+    plan->packedBytes = (long long)bytes;
+    return true;
+}
+
 /* ---- host ---------------------------------------------------------------------------------------------------------- */
+
+/* Wave-wide loads per stage of the PACKED kernels beyond the unpacked kernels' (SPGPU_RAGGED_UNROLL).  A stage of the queue kernel
+ * is a memory round trip and a stage with 16-bit indices is a sixth smaller, so the same bytes in flight could be a third more
+ * columns per round trip; the order of additions would not depend on it (a phase adds its columns in ascending order whatever
+ * the stage size; the chunks of a split sub-group are sized by the unpacked kernels' stage, raggedSplit).  MEASURED with 1
+ * (fp64: 4 loads per stage): 36-44 bytes of scratch per lane, and the target goes from 0.68-0.72 to 0.80-0.83 ms (band) -- a
+ * spill is re-read behind a vmcnt(0) wait, which drains the prefetch at every item.  0 it stays. */
+#ifndef SPGPU_PACKED_MORE_UNROLL
+#define SPGPU_PACKED_MORE_UNROLL 0
+#endif
 
 static size_t roundUp16(size_t v)
 {
@@ -226,11 +351,14 @@ static void startPlan(spgpuHandle_t handle, SpgpuSpmvPlan* plan, hipStream_t str
  * mustLaunch: the caller has no deep list for this stream -- without a ready plan the same kernel runs with NO plan: nothing
  * is listed, every sub-group deeper than the cap is worked off by its own block behind its stream, no x tile.  Stateless,
  * slower, the same bits.
- * prepareOnly (spgpu?SpmvPrepare): nothing is launched but the analysis, and that is waited for: true = the plan is ready.
+ * prepareMode 1 (spgpu?SpmvPrepare): nothing is launched but the analysis, and that is waited for: true = the plan is ready.
+ * prepareMode 2 (spgpu?SpmvFreeze): the same, and the plan gets its 16-bit copy of the column indices (packPlan): true = the
+ * matrix is frozen -- later launches read 2 bytes of index per stored entry instead of 4 (raggedSpmvKernel<..., PACKED>).
  */
 template <typename T, bool IS_HELL>
-bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled, bool mustLaunch, bool prepareOnly)
+bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled, bool mustLaunch, int prepareMode)
 {
+    const bool prepareOnly = prepareMode != 0;
     constexpr int RPL = 16 / (int)sizeof(T);
     constexpr int UNROLL = SPGPU_RAGGED_UNROLL(RPL);
     const SpgpuTuning* tune = spgpuTuning();
@@ -243,6 +371,7 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
     a.planDeepSubs = nullptr;
     a.planDeep = 0;
     a.planFlags = nullptr;
+    a.planPacked = nullptr;
     int perBlock = tune->planDeepPerBlock;
     perBlock = perBlock < 1 ? 1 : (perBlock > kPlanDeepMost ? kPlanDeepMost : perBlock);
     a.planDeepPerBlock = perBlock;
@@ -267,7 +396,16 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
         if (!tiled) {
             SPGPU_PLANNED(4, 0, 16, 0);
         } else if constexpr (sizeof(T) <= 8) {
-            if (staged && shape == 4)
+#define SPGPU_PLANNED_PACKED(WAVES, TILE, SUBS, ZB)                                                                   \
+    hipLaunchKernelGGL((raggedSpmvKernel<T, RPL, IS_HELL, UNROLL + SPGPU_PACKED_MORE_UNROLL, WAVES, TILE, SUBS, true, ZB, true, true>), dim3(grid), dim3((WAVES) * kWave), 0, stream, a)
+            if (a.planPacked) { /* a frozen matrix: 16-bit indices */
+                if (staged && shape == 4)
+                    SPGPU_PLANNED_PACKED(8, 49152, 64, 17408);
+                else if (staged)
+                    SPGPU_PLANNED_PACKED(8, 49152, 32, 17408);
+                else
+                    SPGPU_PLANNED_PACKED(8, 65536, 32, 0);
+            } else if (staged && shape == 4)
                 SPGPU_PLANNED(8, 49152, 64, 17408);
             else if (staged)
                 SPGPU_PLANNED(8, 49152, 32, 17408);
@@ -277,6 +415,7 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
             SPGPU_PLANNED(8, 65536, 32, 0);
         }
 #undef SPGPU_PLANNED
+#undef SPGPU_PLANNED_PACKED
     };
 
     /* a captured launch would carry the plan's addresses for as long as the graph lives; plans are retired: no plan there */
@@ -325,6 +464,13 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
                     plan->state = SPGPU_PLAN_READY;
                 }
                 launched = plan->state == SPGPU_PLAN_READY;
+                if (prepareMode == 2) { /* freeze: true = the plan has its 16-bit indices */
+                    if (launched && !plan->packed && tiled && sizeof(T) <= 8 && (subs == 64 || subs == 32))
+                        (void)packPlan<IS_HELL>(plan, handle, stream);
+                    launched = launched && plan->packed != nullptr;
+                    if (launched)
+                        h->planFreezes += 1;
+                }
             } else if (plan->state == SPGPU_PLAN_READY) {
                 const size_t blockBytes = roundUp16((size_t)plan->blocks * sizeof(SpgpuPlanBlock)), countBytes = roundUp16((size_t)plan->blocks * sizeof(int));
                 a.planBlocks = static_cast<const SpgpuPlanBlock*>(plan->device);
@@ -332,6 +478,8 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
                 a.planDeep = plan->deep;
                 a.planMainBlocks = plan->blocks;
                 a.planFlags = plan->pinned;
+                if (tiled && sizeof(T) <= 8)
+                    a.planPacked = static_cast<const unsigned short*>(plan->packed);
                 launch(); /* (under the lock: a retirement on another host thread waits for this launch to be queued) */
                 plan->uses += 1;
                 h->planUses += 1;
@@ -347,14 +495,14 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
     return launched;
 }
 
-template bool launchPlanned<float, true>(spgpuHandle_t, hipStream_t, const SlabArgs<float>&, int, bool, bool, bool);
-template bool launchPlanned<float, false>(spgpuHandle_t, hipStream_t, const SlabArgs<float>&, int, bool, bool, bool);
-template bool launchPlanned<double, true>(spgpuHandle_t, hipStream_t, const SlabArgs<double>&, int, bool, bool, bool);
-template bool launchPlanned<double, false>(spgpuHandle_t, hipStream_t, const SlabArgs<double>&, int, bool, bool, bool);
-template bool launchPlanned<cfloat, true>(spgpuHandle_t, hipStream_t, const SlabArgs<cfloat>&, int, bool, bool, bool);
-template bool launchPlanned<cfloat, false>(spgpuHandle_t, hipStream_t, const SlabArgs<cfloat>&, int, bool, bool, bool);
-template bool launchPlanned<cdouble, true>(spgpuHandle_t, hipStream_t, const SlabArgs<cdouble>&, int, bool, bool, bool);
-template bool launchPlanned<cdouble, false>(spgpuHandle_t, hipStream_t, const SlabArgs<cdouble>&, int, bool, bool, bool);
+template bool launchPlanned<float, true>(spgpuHandle_t, hipStream_t, const SlabArgs<float>&, int, bool, bool, int);
+template bool launchPlanned<float, false>(spgpuHandle_t, hipStream_t, const SlabArgs<float>&, int, bool, bool, int);
+template bool launchPlanned<double, true>(spgpuHandle_t, hipStream_t, const SlabArgs<double>&, int, bool, bool, int);
+template bool launchPlanned<double, false>(spgpuHandle_t, hipStream_t, const SlabArgs<double>&, int, bool, bool, int);
+template bool launchPlanned<cfloat, true>(spgpuHandle_t, hipStream_t, const SlabArgs<cfloat>&, int, bool, bool, int);
+template bool launchPlanned<cfloat, false>(spgpuHandle_t, hipStream_t, const SlabArgs<cfloat>&, int, bool, bool, int);
+template bool launchPlanned<cdouble, true>(spgpuHandle_t, hipStream_t, const SlabArgs<cdouble>&, int, bool, bool, int);
+template bool launchPlanned<cdouble, false>(spgpuHandle_t, hipStream_t, const SlabArgs<cdouble>&, int, bool, bool, int);
 
 } // namespace spgpu
 

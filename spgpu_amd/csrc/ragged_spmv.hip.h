@@ -64,10 +64,18 @@ template <typename T> constexpr int kRaggedMostChunks = 49152 / (int)sizeof(T) /
  * computed: lengths, bases, destinations and the depth that decides a sub-group's chunks are read from the matrix; a
  * sub-group deeper than deepCap that the plan does not list (a stale plan) is worked off behind the block's own stream, by
  * the same routine, in the same order of additions. */
-template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int TILE_BYTES, int SUBS, bool DEEP, int ZBYTES = 0, bool PLAN = false>
+/* PACKED (a FROZEN matrix: spgpu?SpmvFreeze, include/spgpu/tuning.h -- the caller has promised that its index arrays stay as they
+ * are): the blocks of rows read their column indices from the plan's 16-bit copy (a.planPacked: offsets from the block's packBase,
+ * slot for slot as in rP) instead of from rP -- 2 bytes per stored entry instead of 4, a sixth of an fp64 matrix' stream.  An offset
+ * is a position in the LDS tile once the tile's base is subtracted; 0xFFFF says "ask rP" (a column out of the 16-bit reach of the
+ * base, or negative).  The same columns, the same x, the same order of additions: the same bits.  The workgroups of deep
+ * sub-groups read rP as ever. */
+template <typename T, int RPL, bool IS_HELL, int UNROLL, int WAVES, int TILE_BYTES, int SUBS, bool DEEP, int ZBYTES = 0, bool PLAN = false, bool PACKED = false>
 __global__ __launch_bounds__(WAVES * kWave) __attribute__((amdgpu_waves_per_eu(4)))
 void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavefront workgroups per CU (what LDS admits) */
 {
+    static_assert(!PACKED || (PLAN && TILE_BYTES > 0 && RPL >= 2), "packed indices come with a plan and a tile; 4- and 8-byte elements");
+    using ColumnWord = typename std::conditional<PACKED, unsigned short, int>::type;
     constexpr int LPC = 32 / RPL;   /* lanes per slab column of a sub-group */
     constexpr int PH = kWave / LPC; /* slab columns per wave-wide load */
     constexpr int STEP = PH * UNROLL;
@@ -354,7 +362,7 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     };
     struct Stage {
         Pack<T, RPL> v[UNROLL];
-        Pack<int, RPL> c[UNROLL];
+        Pack<ColumnWord, RPL> c[UNROLL];
     };
     /* item -> (sub-group, chunk); returns the chunk's first column */
     auto loadItem = [&](int item, Item& it) -> int {
@@ -395,12 +403,15 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
             const int k = kBase + u * PH + phase;
             if (k < it.longest) {
                 st.v[u] = loadPack<true, T, RPL>(a.cM + it.slab + (long long)k * a.valStride);
-                st.c[u] = loadPack<true, int, RPL>(a.rP + it.slab + (long long)k * a.idxStride);
+                if constexpr (PACKED)
+                    st.c[u] = loadPack<true, unsigned short, RPL>(a.planPacked + it.slab + (long long)k * a.idxStride);
+                else
+                    st.c[u] = loadPack<true, int, RPL>(a.rP + it.slab + (long long)k * a.idxStride);
             } else {
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
                     st.v[u].v[t] = zeroOf<T>();
-                    st.c[u].v[t] = a.baseIndex;
+                    st.c[u].v[t] = PACKED ? (ColumnWord)0 : (ColumnWord)a.baseIndex;
                 }
             }
         }
@@ -463,6 +474,8 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
     /* ---- the slice of x (round trip 3; the stages requested just above travel with it) ---------------------------- */
     int tileBase = 0;
     unsigned tileCount = 0;
+    int packBase = 0;       /* PACKED: the column the block's 16-bit words count from, */
+    unsigned packDelta = 0; /* and the same minus the tile's base: word + packDelta = position in the tile */
     if constexpr (XTILE) {
         /* the wavefronts' probes meet: a lane reads ONE of them, the rest is DPP (every lane reading all WAVES of them was
          * 24 LDS reads per lane behind the neighbour's traffic) */
@@ -488,6 +501,10 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
                 tileBase = (int)start;
                 tileCount = (unsigned)tileRoom;
             }
+        }
+        if constexpr (PACKED) {
+            packBase = planned.packBase;
+            packDelta = (unsigned)packBase - (unsigned)tileBase;
         }
         constexpr int PIECE = 16 / (int)sizeof(T);
         constexpr int ROUND = (TILE_ELEMS / PIECE + BLOCK - 1) / BLOCK; /* 16-byte pieces per lane: all in flight at once */
@@ -548,7 +565,32 @@ void raggedSpmvKernel(const SlabArgs<T> a) /* 4 wavefronts per SIMD: two 8-wavef
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int k = cur.kBase + u * PH + phase;
-            if constexpr (XTILE) {
+            if constexpr (PACKED) {
+                bool outside = false;
+                unsigned at[RPL];
+#pragma unroll
+                for (int t = 0; t < RPL; ++t) {
+                    const unsigned word = cur.st.c[u].v[t];
+                    use[u][t] = k < cur.len[t];
+                    at[t] = word + packDelta; /* packBase + word - tileBase */
+                    const bool inside = at[t] < tileCount && word != 0xFFFFu;
+                    outside |= use[u][t] && !inside;
+                    xv[u][t] = tile[inside ? at[t] : 0u];
+                }
+                if (__ballot(outside) != 0ull) { /* beside the tile, or beyond the 16 bits: rare, and the one place that asks rP */
+#pragma unroll
+                    for (int t = 0; t < RPL; ++t) {
+                        const unsigned word = cur.st.c[u].v[t];
+                        if (use[u][t] && !(at[t] < tileCount && word != 0xFFFFu)) {
+                            int col = packBase + (int)word;
+                            if (word == 0xFFFFu)
+                                col = a.rP[(long long)bases[cur.s * LPC + sub] + (long long)k * a.idxStride + t] - a.baseIndex;
+                            use[u][t] = col >= 0;
+                            xv[u][t] = x[col >= 0 ? col : 0];
+                        }
+                    }
+                }
+            } else if constexpr (XTILE) {
                 bool outside = false;
                 unsigned at[RPL];
 #pragma unroll

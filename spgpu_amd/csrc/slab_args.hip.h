@@ -52,6 +52,8 @@ template <typename T> struct SlabArgs {
     int planDeepPerBlock;             /* deep sub-groups per such workgroup (<= kPlanDeepMost) */
     int planDeepStride;               /* such a workgroup at every planDeepStride-th place of the grid, from the front (0: all of them at the end) */
     int* planFlags;                   /* pinned; [1] = 1: a kernel found the plan contradicting the matrix */
+    const unsigned short* planPacked; /* raggedSpmvKernel<..., PACKED>: a frozen matrix' column indices as 16-bit offsets from the block's
+                                       * packBase, slot for slot as in rP (0xFFFF: ask rP); NULL: the matrix is not frozen */
 };
 
 constexpr int kBlockThreads = 256;
@@ -110,7 +112,7 @@ struct ColumnProbe {
 
 
 /* planned_spmv.hip: the ordered SpMV with the matrix's plan, if it has one that is ready (true: launched, nothing follows) */
-template <typename T, bool IS_HELL> bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled, bool mustLaunch, bool prepareOnly);
+template <typename T, bool IS_HELL> bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& in, int shape, bool tiled, bool mustLaunch, int prepareMode);
 
 constexpr int kDeepChunk = 64; /* columns per deep item; measured: items of 32 / 64 / 128 columns and stages of 16 / 32 within 8 % -- the kernel is bound by the lines its gathers pull */
 

@@ -58,6 +58,7 @@ typedef struct SpgpuPrivateHandle {
     int planGraves;
     unsigned planClock;
     int planUses, planBuilds, planStales;           /* diagnostics (spgpuSpmvPlanCounts) */
+    int planFreezes;                                /* spgpu?SpmvFreeze calls that left a matrix frozen */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8 /* + one more group of words behind them for spgpu?SpmvForm, and one for the deep list's overflow report */
 #define SPGPU_FEEDBACK_SAMPLES 4
@@ -129,7 +130,7 @@ typedef struct SpgpuPlanBlock {
     int probed;          /* how many rows took part (0: no tile) */
     unsigned long long deepMask; /* bit s: sub-group s of the block is in the deep list */
     int firstDeep;       /* index of its first entry there */
-    int reserved;
+    int packBase;        /* frozen matrices (spgpu?SpmvFreeze): the column the block's 16-bit packed indices count from */
 } SpgpuPlanBlock;
 typedef struct SpgpuSpmvPlan {
     /* key: the arrays the analysis read, and what it assumed */
@@ -144,7 +145,10 @@ typedef struct SpgpuSpmvPlan {
     int blocks;     /* blocks of `subs` sub-groups */
     int deep;       /* deep sub-groups (read from pinned[0] once the analysis has completed) */
     void* device;   /* one allocation: SpgpuPlanBlock[blocks] | int counts[blocks] | int deepSubs[sub-groups] */
-    int* pinned;    /* [0] deep sub-groups, written by the analysis; [1] != 0: a kernel found the plan stale */
+    long long packedBytes;
+    void* packed;   /* frozen matrices only (spgpu?SpmvFreeze, include/spgpu/tuning.h), else NULL: the column indices of the rows the blocks walk
+                     * themselves as 16-bit offsets from the block's packBase, slot for slot as in rP (0xFFFF: ask rP) */
+    int* pinned;    /* [0] deep sub-groups, written by the analysis; [1] != 0: a kernel found the plan stale; [2] slots of the index array (freeze) */
     hipEvent_t built;
 } SpgpuSpmvPlan;
 enum { SPGPU_PLAN_EMPTY = 0, SPGPU_PLAN_BUILDING = 1, SPGPU_PLAN_READY = 2, SPGPU_PLAN_GIVEN_UP = 3 };
