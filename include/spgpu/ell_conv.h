@@ -48,9 +48,7 @@ void ellToOell(int* rIdx, void* dstEllValues, int* dstEllIndices, int* dstRs, co
  *                their own, SPGPU_OELL_LONG_WINDOW_FACTOR times as large (one window when window <= 0): a handful of very
  *                long rows otherwise sets the depth of one hack per window, and sorted over the whole matrix the 32 rows of
  *                one of their hacks would come from everywhere (every x gather a cache line from memory). */
-#ifndef SPGPU_OELL_LONG_WINDOW_FACTOR
 #define SPGPU_OELL_LONG_WINDOW_FACTOR 32
-#endif
 void oellOrder(int* rIdx, int* dstRs, const int* srcRs, int rowsCount, int window, int longRows);
 /* The same with the windows of the shorter rows ALIGNED: when rows are set aside (longRows > 0, window > 0) the others are cut
  * into runs of `window` of them -- counted among themselves, not by original row number -- placed so that every window but the

@@ -11,7 +11,8 @@ blocks per XCD.  EXP_PATTERNS = near,band,random (power-law) or near2048,near512
 EXP_ORDERS = window:longRows pairs (2048:256,...); EXP_ONLY_WINDOWED=1 skips the plain and globally sorted layouts;
 EXP_WINDOWS_FOR_ALL=1 runs the windowed orders on scattered columns too; EXP_ALIGNED=1 orders the rows with spgpuOellOrderAlignedDevice
 (windows counted among the short rows: one window = one workgroup; DESIGN.md section 3.1);
-EXP_DROP_RIDX=1 runs the ordered matrix without its row order (timing only).  SPGPU_* knobs pass through.
+EXP_DROP_RIDX=1 runs the ordered matrix without its row order (timing only); EXP_FREEZE=1 freezes every ordered matrix first
+(spgpuHellSpmvFreeze: 16-bit column indices).  SPGPU_* knobs pass through.
 """
 import ctypes as C
 import os
@@ -88,6 +89,9 @@ def run(h, label, forms):
         r_idx = torch.arange(rows, dtype=torch.int32, device="cuda")
     call = lambda: capi.hellspmv[letter](handle, p(z), None, one, p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]),
                                          None if os.environ.get("EXP_DROP_RIDX") else p(r_idx), 32, rows, p(x), zero, 0)
+    if os.environ.get("EXP_FREEZE") and r_idx is not None:             # spgpuHellSpmvFreeze first: 16-bit column indices (include/spgpu/tuning.h)
+        said = capi.spgpuHellSpmvFreeze(handle, capi.TYPE_CODE[letter], p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]), p(r_idx), rows, 0)
+        label = f"{label} FROZEN({said})"
     for full in forms:
         name = full
         full, _, keep = full.partition("%")         # "auto%32": SPGPU_DEEP_KEEP for this run (same matrix, same process)
