@@ -71,6 +71,9 @@ int spgpuDeepListsRecycled(spgpuHandle_t handle);
  * A stale plan is noticed by the kernels and rebuilt by the next call.  Launches captured into a HIP graph never use a plan.
  *   SPGPU_PLAN=0                 no plans
  *   SPGPU_PLAN_DEEP_PER_BLOCK    deep sub-groups per workgroup of theirs (default 8, 1 .. 8)
+ *   SPGPU_PLAN_DEEP_RUNS         1 (default): such a workgroup takes a RUN of consecutive deep sub-groups of the list -- after an
+ *                                ordering these are neighbours in the matrix (one window of set-aside long rows), so their gathers
+ *                                of x meet in one L2; 0: every N-th sub-group (the dealing of the first planned kernels)
  *   SPGPU_PLAN_DEEP_SPREAD       those workgroups are spread over the first N per cent of the grid (default 60; 0: all in front;
  *                                -1: all behind the blocks of rows)
  * spgpuSpmvPlanCounts: launches that ran with a plan, analyses started, plans found stale (any pointer may be NULL).

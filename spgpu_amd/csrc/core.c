@@ -530,6 +530,7 @@ void spgpuTuningReload(void)
     t.plan = envInt("SPGPU_PLAN", 1);
     t.planDeepSpread = envInt("SPGPU_PLAN_DEEP_SPREAD", 60);
     t.planDeepPerBlock = envInt("SPGPU_PLAN_DEEP_PER_BLOCK", 8);
+    t.planDeepRuns = envInt("SPGPU_PLAN_DEEP_RUNS", 1);
     t.stageLate = envInt("SPGPU_STAGE_LATE", 1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);

@@ -1603,7 +1603,7 @@ static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     a.planBlocks = nullptr;
     a.planDeepSubs = nullptr;
     a.planFlags = nullptr;
-    a.planDeep = a.planMainBlocks = a.planDeepPerBlock = a.planDeepStride = 0;
+    a.planDeep = a.planMainBlocks = a.planDeepPerBlock = a.planDeepStride = a.planDeepRuns = 0;
     launchSlabFamily<T, true>(handle, a);
     spgpuDebugCheck(handle, "hellspmv");
 }
@@ -1637,7 +1637,7 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
     a.planBlocks = nullptr;
     a.planDeepSubs = nullptr;
     a.planFlags = nullptr;
-    a.planDeep = a.planMainBlocks = a.planDeepPerBlock = a.planDeepStride = 0;
+    a.planDeep = a.planMainBlocks = a.planDeepPerBlock = a.planDeepStride = a.planDeepRuns = 0;
     launchSlabFamily<T, false>(handle, a);
     spgpuDebugCheck(handle, "ellspmv");
 }

@@ -375,6 +375,7 @@ bool launchPlanned(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& 
     int perBlock = tune->planDeepPerBlock;
     perBlock = perBlock < 1 ? 1 : (perBlock > kPlanDeepMost ? kPlanDeepMost : perBlock);
     a.planDeepPerBlock = perBlock;
+    a.planDeepRuns = tune->planDeepRuns;
     a.planDeepStride = 0;
     const long long subGroups = ((long long)a.rows + 31) / 32;
     a.planMainBlocks = (int)((subGroups + subs - 1) / subs);

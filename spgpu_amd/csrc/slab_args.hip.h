@@ -50,6 +50,7 @@ template <typename T> struct SlabArgs {
     int planDeep;
     int planMainBlocks;               /* workgroups that own blocks of rows; the rest of the grid owns deep sub-groups */
     int planDeepPerBlock;             /* deep sub-groups per such workgroup (<= kPlanDeepMost) */
+    int planDeepRuns;                 /* 0: such a workgroup takes sub-groups deepId, deepId + deepBlocks, ... of the list; 1: a run of consecutive ones */
     int planDeepStride;               /* such a workgroup at every planDeepStride-th place of the grid, from the front (0: all of them at the end) */
     int* planFlags;                   /* pinned; [1] = 1: a kernel found the plan contradicting the matrix */
     const unsigned short* planPacked; /* raggedSpmvKernel<..., PACKED>: a frozen matrix' column indices as 16-bit offsets from the block's
