@@ -85,6 +85,51 @@ def committed_traffic(rows, nnz_per_row, pattern, rhs=None):
     return best
 
 
+def live_traffic(args, kernel_words=("SpmvKernel",), extra=()):
+    """HBM bytes per launch of the headline kernel, counted in THIS run: two child processes of this very file (--no-extras, 10
+    steps) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace` -- separate passes, the counters
+    corrected as MI355X_MICROARCH.md's HBM section says (gfx950: FETCH_SIZE reports half the bytes of wide streaming reads; KiB
+    units).  The children are started as ordinary child processes with python3 itself behind `--` (no exec from a process that holds
+    the GPU, no shell hop).  Returns (bytes, detail) or (None, reason): the caller then falls back to the committed summary."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="spgpu_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", SPGPU_BENCH_INNER="1")
+    seen = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(work, counter.lower())
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", counter.lower(), "--", "python3",
+                   os.path.abspath(__file__), "--no-extras", "--steps", "10", "--warmup", "2", "--rows", str(args.rows),
+                   "--nnz-per-row", str(args.nnz_per_row), "--pattern", args.pattern, *extra]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            except subprocess.TimeoutExpired:
+                return None, f"{counter} pass timed out"
+            per_kernel = {}
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row.get("Counter_Name") == counter and all(w in row["Kernel_Name"] for w in kernel_words):
+                        per_kernel.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            if not per_kernel:
+                return None, f"{counter} pass: no dispatch of the kernel in the counter file (rc {r.returncode}: {r.stderr[-200:]!r})"
+            name, values = max(per_kernel.items(), key=lambda kv: len(kv[1]))   # the kernel of the timed launches: the most dispatches
+            seen[counter] = (name, sum(values) / len(values), len(values))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    read_bytes, write_bytes = 2.0 * seen["FETCH_SIZE"][1] * 1024, seen["WRITE_SIZE"][1] * 1024
+    return int(read_bytes + write_bytes), dict(
+        source="live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE --kernel-trace, separate child runs of this bench.py (--no-extras --steps 10) "
+               "during this run; read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 correction), write bytes = WRITE_SIZE KiB x 1024",
+        kernel=seen["FETCH_SIZE"][0][:160], dispatches_counted=seen["FETCH_SIZE"][2], hbm_read_bytes=int(read_bytes), hbm_write_bytes=int(write_bytes))
+
+
 def vendor():
     """tools/vendor_context.py (rocSPARSE through ctypes), or None: same-node context numbers, never on the path."""
     try:
@@ -685,16 +730,12 @@ def run_spmv(args, rank, world):
                     own = OwnAllocations(dict(cM=h["cM"], rP=h["rP"], hack_offsets=h["hack_offsets"], rS=h["rS"], x=x, z=z))
                     try:
                         torch.cuda.synchronize()
-                        if frozen:
-                            assert freeze(own) == capi.SPGPU_SUCCESS
                         placed = lambda own=own: capi.hellspmv["D"](handle, own["z"], None, C.c_double(1.0), own["cM"], own["rP"], h["hack_size"],
                                                                     own["hack_offsets"], own["rS"], None, args.nnz_per_row, h["rows"], own["x"],
                                                                     C.c_double(0.0), 0)
                         moved.append([round(v, 4) for v in timed_blocks(stream, placed)])
                     finally:
                         torch.cuda.synchronize()
-                        if frozen:
-                            capi.spgpuSpmvThaw(handle, own["rP"])
                         own.free()
                 every = [v for blocks in moved for v in blocks]
                 out["roofline"]["placements_kernel_ms"] = moved
@@ -790,6 +831,21 @@ def run_spmv(args, rank, world):
                               "algorithmic bytes (12 per nonzero, frozen or not) / time / 8 TB/s, time = median over placements of the arrays (ms_spread / frac_spread: every timed block); bar 0.70")
             out["config"]["north_star_target"] = target
             out["target"] = target
+            # the headline kernel's HBM traffic, counted during THIS run (two short child runs under rocprofv3 --pmc; the value read
+            # from the committed summary under profiles/ stays as the fallback and is kept beside it)
+            if world == 1 and not os.environ.get("SPGPU_BENCH_INNER") and not os.environ.get("SPGPU_BENCH_NO_PMC"):
+                committed = out["roofline"]["traffic"]
+                try:
+                    counted, detail = live_traffic(args)
+                except Exception as error:  # noqa: BLE001 - the record does not depend on the profiler
+                    counted, detail = None, repr(error)
+                if counted is not None:
+                    out["roofline"]["traffic"] = counted
+                    out["roofline"]["traffic_source"] = dict(detail, committed_summary_value=committed,
+                                                             over_algorithmic=round(counted / out["roofline"]["algorithmic_bytes_per_launch"], 4))
+                else:
+                    out["roofline"]["traffic_source"] = dict(source="profiles/*_bench_spmv_pmc.json (committed PMC summary of the same workload)",
+                                                             live_attempt=detail)
             if world == 1:
                 # the N = 1 point of the curve `--gpus N` (N > 1) measures: same sharded SpMM step on one rank
                 one = measure_spmm(args, 0, 1, handle, stream, dev, 50, 5)
