@@ -721,6 +721,38 @@ def run_spmv(args, rank, world):
             a2 = hell_algorithmic_bytes(h["nnz"], h["rows"], h["cols"], hacks, beta_nonzero=True)
             extras[f"{args.pattern}_beta0.5"] = dict(gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(a2 / t * 1e-9, 1),
                                                       frac=round(a2 / t * 1e-9 / HBM_PEAK_GBS, 4), ms=round(t * 1e3, 4), form=form_ran(handle))
+            # the headline matrix FROZEN (include/spgpu/tuning.h spgpuHellSpmvFreeze: the caller's promise that the index arrays stay as
+            # they are; the library streams its 16-bit copy of the column indices -- 10 instead of 12 bytes per nonzero): the same
+            # spgpuDhellspmv call, bit-identical result.  `frac` is still ALGORITHMIC bytes (12 per nonzero) / time / peak; the
+            # headline `value` above is the unfrozen call.
+            try:
+                p_ = lambda t: C.c_void_p(t.data_ptr())
+                t0 = time.perf_counter()
+                said = capi.spgpuHellSpmvFreeze(handle, capi.TYPE_CODE["D"], p_(h["cM"]), p_(h["rP"]), h["hack_size"], p_(h["hack_offsets"]), p_(h["rS"]),
+                                                None, h["rows"], 0)
+                torch.cuda.synchronize()
+                freeze_ms = (time.perf_counter() - t0) * 1e3
+                if said == capi.SPGPU_SUCCESS:
+                    uses0 = capi.plan_counts(handle)[0]
+                    blocks_f = timed_blocks(stream, step, blocks=5, launches=max(args.steps // 5, 10))
+                    t = sorted(blocks_f)[len(blocks_f) // 2] * 1e-3
+                    z.zero_()
+                    step()
+                    torch.cuda.synchronize()
+                    out["headline_frozen"] = dict(
+                        ms=round(t * 1e3, 5), gflops=round(flops / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1), frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4),
+                        ms_blocks=spread(blocks_f), streamed_bytes_per_nnz=10, streamed_bytes_per_launch=alg - 2 * h["nnz"],
+                        frac_of_streamed_bytes=round((alg - 2 * h["nnz"]) / t * 1e-9 / HBM_PEAK_GBS, 4),
+                        frozen_copy_GB=round(capi.spgpuSpmvFrozenBytes(handle) * 1e-9, 3), freeze_ms=round(freeze_ms, 1),
+                        calls_from_the_frozen_record=capi.plan_counts(handle)[0] - uses0, form=form_ran(handle),
+                        parity=spot_check_hell(h, x, y, z, 1.0, 0.0),
+                        what="the headline matrix and call after spgpuHellSpmvFreeze: frac = algorithmic bytes (12 per nonzero) / time / 8 TB/s as for "
+                             "`roofline`; frac_of_streamed_bytes = what the frozen kernel actually streams (10 per nonzero) / time / 8 TB/s")
+                else:
+                    out["headline_frozen"] = dict(status=said)
+                capi.spgpuSpmvThaw(handle, p_(h["rP"]))
+            except Exception as error:  # noqa: BLE001 - an extra must not take the headline record down
+                out["headline_frozen"] = dict(error=repr(error))
             # the headline launches once more with the arrays in allocations of their own, `--placements` times: how far does the
             # placement of the caller's arrays move THIS kernel on this card?  (`value` stays what the contract
             # says: the K timed steps above, on the arrays as they were built.)
@@ -855,7 +887,7 @@ def run_spmv(args, rank, world):
         elif "cpu_baseline" not in out:
             out["cpu_baseline"] = None
         first = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                 "data", "config", "roofline", "target", "cpu_baseline", "parity", "device"]
+                 "data", "config", "roofline", "target", "headline_frozen", "cpu_baseline", "parity", "device"]
         out = {**{key: out[key] for key in first if key in out}, **{key: value for key, value in out.items() if key not in first}}
         print(json.dumps(out), flush=True)
     capi.spgpuDestroy(handle)

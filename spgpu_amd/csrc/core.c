@@ -425,6 +425,22 @@ SpgpuSpmvPlan* spgpuPlanRecord(spgpuHandle_t pHandle, const SpgpuSpmvPlan* key)
     return oldest;
 }
 
+/* Lock held.  The record with this key, or NULL: looks, never makes room. */
+SpgpuSpmvPlan* spgpuPlanFind(spgpuHandle_t pHandle, const SpgpuSpmvPlan* key)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    if (!h->plans)
+        return NULL;
+    for (int i = 0; i < SPGPU_PLANS; ++i) {
+        SpgpuSpmvPlan* p = &h->plans[i];
+        if (p->rows > 0 && samePlanKey(p, key)) {
+            p->clock = ++h->planClock;
+            return p;
+        }
+    }
+    return NULL;
+}
+
 void spgpuSpmvPlanCounts(spgpuHandle_t pHandle, int* uses, int* builds, int* stales)
 {
     SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
@@ -451,6 +467,9 @@ int spgpuSpmvThaw(spgpuHandle_t pHandle, const int* rP)
             thawed += 1;
         }
     }
+    h->planFrozenSlabs = 0;
+    for (int i = 0; i < SPGPU_PLANS; ++i)
+        h->planFrozenSlabs += (h->plans[i].rows > 0 && h->plans[i].subs < 0 && h->plans[i].packed) ? 1 : 0;
     pthread_mutex_unlock(&h->formLock);
     return thawed ? SPGPU_SUCCESS : SPGPU_UNSUPPORTED;
 }

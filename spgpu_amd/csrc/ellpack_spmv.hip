@@ -78,11 +78,19 @@ __device__ inline long long sampleGroup(long long groups, int q)
  * STRIPS compiles the strip-load form in (see consume below); the form without it exists as well because the mere
  *        presence of the second loop costs the gather loop ~8 % on scattered matrices (measured; same instruction
  *        counts, so a placement / allocation effect), and the host picks per matrix (launchSlabFamily).
+ * PACKED a FROZEN matrix without a row order (spgpu?SpmvFreeze, include/spgpu/tuning.h; frozen_slab below): the stage loads read
+ *        the column indices from the library's 16-bit copy (a.planPacked: offsets from the group's a.packBases[group], slot for
+ *        slot as in rP; 0xFFFF = "ask rP") -- 2 bytes per stored entry instead of 4.  Same columns, same order: same bits.  The
+ *        rare paths (whole-wave tail rows, the sample wavefronts' span) read rP itself, which the caller's promise keeps valid.
  */
 template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PIPE, bool TAIL, int XPOLICY = 0, bool STRIPS = false,
-          int BLOCK = kBlockThreads, int TILE_BYTES = 0, bool DEEP = false, int GPW = 1, int TAIL_EVERY = 0>
+          int BLOCK = kBlockThreads, int TILE_BYTES = 0, bool DEEP = false, int GPW = 1, int TAIL_EVERY = 0, bool PACKED = false>
 __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
 {
+    /* (PACKED, measured: the fp64 kernel needs 140 VGPRs -- 3 wavefronts per SIMD, as the unpacked kernel's 146.  Capped at 128 for a
+     * fourth wavefront -- amdgpu_waves_per_eu(4, 4) -- it spills 52-64 bytes per lane into its stage loop: 0.575 -> 0.896 ms.) */
+    static_assert(!PACKED || (TILE_BYTES == 0 && !DEEP && RPL >= 2 && XPOLICY == 0), "packed indices: the gather and strip forms of 4- and 8-byte elements");
+    using ColumnWord = typename std::conditional<PACKED, unsigned short, int>::type;
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
     constexpr int GROUP_ROWS = LPC * RPL;   /* rows owned by the wavefront */
     constexpr int WAVES = BLOCK / kWave;
@@ -271,6 +279,10 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
 
     const T* __restrict__ vals = a.cM + slab;
     const int* __restrict__ idxs = a.rP + slab;
+    /* PACKED: the group's 16-bit words count from here (wave-uniform: one scalar load) */
+    int packBase = 0;
+    if constexpr (PACKED)
+        packBase = a.packBases[group];
 
     /* One stage = UNROLL slab columns per phase: the coefficient/index loads of a stage are
      * issued back to back (fetch), its x gathers and multiply-adds follow (consume).  With
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
      * of stage s+1 are in flight while the gathers of stage s wait for x. */
     struct Stage {
         Pack<T, RPL> v[UNROLL];
-        Pack<int, RPL> c[UNROLL];
+        Pack<ColumnWord, RPL> c[UNROLL];
     };
     auto fetch = [&](int kBase, Stage& s) {
 #pragma unroll
@@ -286,14 +298,28 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
             const int k = kBase + u * PH + phase;
             if (k < laneLongest) {
                 s.v[u] = loadPack<NT, T, RPL>(vals + (long long)k * a.valStride);
-                s.c[u] = loadPack<NT, int, RPL>(idxs + (long long)k * a.idxStride);
+                if constexpr (PACKED)
+                    s.c[u] = loadPack<NT, unsigned short, RPL>(a.planPacked + slab + (long long)k * a.idxStride);
+                else
+                    s.c[u] = loadPack<NT, int, RPL>(idxs + (long long)k * a.idxStride);
             } else {
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
                     s.v[u].v[t] = zeroOf<T>();
-                    s.c[u].v[t] = a.baseIndex;
+                    s.c[u].v[t] = PACKED ? (ColumnWord)0xFFFF : (ColumnWord)a.baseIndex;
                 }
             }
+        }
+    };
+    /* the 0-based column of a stage's word (PACKED: base + offset; an escape asks rP) */
+    auto columnOf = [&](const Stage& s, int u, int t, int k) -> int {
+        if constexpr (PACKED) {
+            const unsigned word = s.c[u].v[t];
+            if (word == 0xFFFFu)
+                return k < len[t] ? idxs[t + (long long)k * a.idxStride] - a.baseIndex : 0;
+            return packBase + (int)word;
+        } else {
+            return s.c[u].v[t] - a.baseIndex;
         }
     };
     /* consume(form, kBase, stage, between): the x values of the stage, then `between()`, then the multiply-adds.
@@ -319,7 +345,7 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
                 const bool present = k < len[0];
                 /* an absent strip still issues its load (no divergence in the stage): from the coefficient array, which
                  * holds at least one whole strip whenever a stage runs -- x itself may be shorter than RPL elements */
-                const Pack<T, RPL> w = loadPackElementAligned<T, RPL>(present ? x + (s.c[u].v[0] - a.baseIndex) : a.cM);
+                const Pack<T, RPL> w = loadPackElementAligned<T, RPL>(present ? x + (PACKED ? packBase + (int)s.c[u].v[0] : (int)s.c[u].v[0] - a.baseIndex) : a.cM);
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
                     use[u][t] = present;
@@ -350,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
             } else {
 #pragma unroll
                 for (int t = 0; t < RPL; ++t) {
-                    const int col = s.c[u].v[t] - a.baseIndex;
+                    const int col = columnOf(s, u, t, k);
                     use[u][t] = k < len[t] && col >= 0;
                     xv[u][t] = loadX<XPOLICY>(x + (use[u][t] ? col : 0));
                 }
@@ -372,9 +398,14 @@ __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
             const int k = kBase + u * PH + phase;
             const bool present = k < len[0];
 #pragma unroll
-            for (int t = 0; t < RPL; ++t) /* all rows of the strip present with consecutive columns, or all absent */
-                scattered |= (k < len[t]) != present ||
-                             (present && (s.c[u].v[0] - a.baseIndex < 0 || s.c[u].v[t] != s.c[u].v[0] + t));
+            for (int t = 0; t < RPL; ++t) { /* all rows of the strip present with consecutive columns, or all absent */
+                if constexpr (PACKED) /* (an escape -- 0xFFFF: the column is in rP -- is never part of a strip; a word's column is >= 0) */
+                    scattered |= (k < len[t]) != present ||
+                                 (present && (s.c[u].v[t] == 0xFFFFu || (unsigned)s.c[u].v[t] != (unsigned)s.c[u].v[0] + (unsigned)t));
+                else
+                    scattered |= (k < len[t]) != present ||
+                                 (present && (s.c[u].v[0] - a.baseIndex < 0 || s.c[u].v[t] != s.c[u].v[0] + t));
+            }
         }
         return __ballot(scattered) == 0ull;
     };
@@ -1243,6 +1274,203 @@ static void launchFormProbe(hipStream_t stream, const SlabArgs<T>& a, bool wideO
     hipLaunchKernelGGL((formProbeKernel<T, 1, 2, IS_HELL, 8>), dim3(3), dim3(kWave), 0, stream, a);
 }
 
+/* ---- frozen matrices WITHOUT a row order (spgpu?SpmvFreeze with rIdx == NULL, include/spgpu/tuning.h) ------------------------
+ * The ordered matrices' frozen form lives with their plan (planned_spmv.hip).  A matrix that runs in the default kernels --
+ * BASELINE configs[1], the headline -- gets the same: a 16-bit copy of its column indices, counted per GROUP of rows (the
+ * rows one wavefront of slabSpmvKernel owns: 128 for the 8-byte types, 32 for fp32) from the group's lowest column, 0xFFFF where
+ * a column lies 65 535 or more above it (or is negative).  The record sits in the handle's plan table under the arrays'
+ * addresses with subs = -groupRows (no analysis, no blocks: `device` holds the groups' bases).  A matrix with more than one
+ * escape in a hundred entries is not frozen: its columns are scattered, the gathers bound its SpMV, and every escape costs the
+ * rP word the copy was to save. */
+template <bool IS_HELL>
+__global__ __launch_bounds__(256) void slabPackKernel(const int* __restrict__ rP, const int* __restrict__ rS, const int* __restrict__ hackOffsets,
+                                                     int hackSize, long long idxStride, int maxNnz, int rows, int baseIndex, int groupRows,
+                                                     int* __restrict__ packBases, unsigned short* __restrict__ packed, unsigned long long* counts)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long group = (long long)blockIdx.x * (256 / kWave) + (threadIdx.x >> 6); /* a wavefront per group */
+    const long long groupRow0 = group * groupRows;
+    if (groupRow0 >= rows)
+        return;
+    constexpr int MOST = 2; /* rows per lane: groups of up to 128 rows */
+    long long at[MOST];
+    int len[MOST];
+    int lowest = 0x7fffffff;
+    for (int j = 0; j < MOST; ++j) {
+        const long long r = groupRow0 + lane + j * kWave;
+        len[j] = (lane + j * kWave < groupRows && r < rows) ? (rS ? rS[r] : maxNnz) : 0;
+        at[j] = 0;
+        if (len[j] > 0) {
+            if constexpr (IS_HELL) {
+                const unsigned u = (unsigned)r, hs = (unsigned)hackSize;
+                at[j] = (long long)((unsigned)hackOffsets[u / hs] + u % hs);
+            } else {
+                at[j] = r;
+            }
+        }
+        for (int k = 0; k < len[j]; ++k) {
+            const int col = rP[at[j] + (long long)k * idxStride] - baseIndex;
+            lowest = (col >= 0 && col < lowest) ? col : lowest;
+        }
+    }
+    lowest = waveMin(lowest);
+    const int base = lowest == 0x7fffffff ? 0 : lowest;
+    if (lane == 0)
+        packBases[group] = base;
+    unsigned entries = 0, escapes = 0;
+    for (int j = 0; j < MOST; ++j) {
+        for (int k = 0; k < len[j]; ++k) {
+            const long long slot = at[j] + (long long)k * idxStride;
+            const int col = rP[slot] - baseIndex;
+            const long long off = (long long)col - base;
+            const bool fits = col >= 0 && off < 0xFFFF;
+            packed[slot] = fits ? (unsigned short)off : (unsigned short)0xFFFF;
+            entries += 1;
+            escapes += fits ? 0 : 1;
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+        entries += (unsigned)laneXor((int)entries, m);
+        escapes += (unsigned)laneXor((int)escapes, m);
+    }
+    if (lane == 0) {
+        atomicAdd(&counts[0], (unsigned long long)entries);
+        atomicAdd(&counts[1], (unsigned long long)escapes);
+    }
+}
+
+__global__ __launch_bounds__(kWave) void slabSlotsKernel(const int* __restrict__ rS, const int* __restrict__ hackOffsets, int hackSize, int rows, unsigned long long* out)
+{
+    /* HELL does not state its slot count (hell.c:64,75: no trailing total): last hack's offset + hackSize x its longest row */
+    const int lastHack = (rows - 1) / hackSize;
+    int longest = 0;
+    for (long long r = (long long)lastHack * hackSize + threadIdx.x; r < rows; r += kWave)
+        longest = rS[r] > longest ? rS[r] : longest;
+    longest = waveMax(longest);
+    if (threadIdx.x == 0)
+        out[0] = (unsigned long long)(unsigned)hackOffsets[lastHack] + (unsigned long long)hackSize * (unsigned)longest;
+}
+
+template <typename T> static SpgpuSpmvPlan slabPlanKey(const SlabArgs<T>& a, int groupRows)
+{
+    SpgpuSpmvPlan key{};
+    key.rP = a.rP;
+    key.rS = a.rS;
+    key.rIdx = nullptr;
+    key.hackOffsets = a.hackOffsets;
+    key.idxStride = a.idxStride;
+    key.rows = a.rows;
+    key.hackSize = a.hackSize;
+    key.baseIndex = a.baseIndex;
+    key.maxNnz = a.maxNnz;
+    key.deepCap = 0;
+    key.subs = -groupRows;
+    return key;
+}
+
+/* spgpu?SpmvFreeze of a matrix without a row order: synchronous; true = frozen (or was already). */
+template <typename T, bool IS_HELL>
+static bool freezeSlab(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<T>& a, int groupRows)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(handle);
+    const SpgpuSpmvPlan key = slabPlanKey(a, groupRows);
+    spgpuPlanLock(handle);
+    SpgpuSpmvPlan* plan = spgpuPlanRecord(handle, &key);
+    bool frozen = plan && plan->packed && plan->state == SPGPU_PLAN_READY;
+    if (plan && !frozen && plan->state != SPGPU_PLAN_GIVEN_UP) {
+        const long long groups = ((long long)a.rows + groupRows - 1) / groupRows;
+        const size_t baseBytes = ((size_t)groups * sizeof(int) + 255) / 256 * 256;
+        void *device = nullptr, *packed = nullptr;
+        int previous = 0;
+        (void)hipGetDevice(&previous);
+        (void)hipSetDevice(handle->device);
+        bool ok = hipMalloc(&device, baseBytes + 256) == hipSuccess;
+        unsigned long long* counts = ok ? reinterpret_cast<unsigned long long*>(static_cast<char*>(device) + baseBytes) : nullptr;
+        unsigned long long said[2] = {0, 0};
+        long long slots = IS_HELL ? 0 : a.idxStride * (long long)a.maxNnz;
+        if (ok && IS_HELL) {
+            hipLaunchKernelGGL(slabSlotsKernel, dim3(1), dim3(kWave), 0, stream, a.rS, a.hackOffsets, a.hackSize, a.rows, counts);
+            ok = hipMemcpyAsync(said, counts, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                 hipStreamSynchronize(stream) == hipSuccess;
+            slots = (long long)said[0];
+        }
+        ok = ok && slots > 0;
+        const size_t packedBytes = ok ? ((size_t)slots * sizeof(unsigned short) + 255) / 256 * 256 : 0;
+        ok = ok && hipMalloc(&packed, packedBytes) == hipSuccess;
+        (void)hipSetDevice(previous);
+        if (ok) {
+            if (spgpuTuning()->poisonScratch)
+                (void)hipMemsetAsync(packed, 0xA5, packedBytes, stream);
+            (void)hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), stream);
+            hipLaunchKernelGGL((slabPackKernel<IS_HELL>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, stream, a.rP, a.rS, a.hackOffsets, a.hackSize,
+                               a.idxStride, a.maxNnz, a.rows, a.baseIndex, groupRows, static_cast<int*>(device), static_cast<unsigned short*>(packed), counts);
+            ok = hipMemcpyAsync(said, counts, sizeof(said), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+        }
+        if (ok && said[1] * 100ull <= said[0]) { /* at most one escape in a hundred entries */
+            plan->device = device;
+            plan->packed = packed;
+            plan->packedBytes = (long long)packedBytes;
+            plan->blocks = 0;
+            plan->deep = 0;
+            plan->uses = 0;
+            plan->state = SPGPU_PLAN_READY;
+            h->planFreezes += 1;
+            frozen = true;
+        } else {
+            (void)hipGetLastError();
+            if (device)
+                (void)hipFree(device);
+            if (packed)
+                (void)hipFree(packed);
+        }
+    }
+    h->planFrozenSlabs = 0;
+    if (h->plans)
+        for (int i = 0; i < SPGPU_PLANS; ++i)
+            h->planFrozenSlabs += (h->plans[i].rows > 0 && h->plans[i].subs < 0 && h->plans[i].packed) ? 1 : 0;
+    spgpuPlanUnlock(handle);
+    return frozen;
+}
+
+/* The SpMV side: a.planPacked / a.packBases of the matrix' frozen record, if it has one (else they stay NULL).  Not inside a
+ * stream capture: a graph would carry the copy's address beyond a Thaw. */
+template <typename T>
+static void findFrozenSlab(spgpuHandle_t handle, hipStream_t stream, SlabArgs<T>& a, int groupRows)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(handle);
+    a.planPacked = nullptr;
+    a.packBases = nullptr;
+    if (__atomic_load_n(&h->planFrozenSlabs, __ATOMIC_RELAXED) <= 0)
+        return;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return;
+    }
+    const SpgpuSpmvPlan key = slabPlanKey(a, groupRows);
+    spgpuPlanLock(handle);
+    SpgpuSpmvPlan* plan = spgpuPlanFind(handle, &key);
+    if (plan && plan->packed && plan->state == SPGPU_PLAN_READY) {
+        a.planPacked = static_cast<const unsigned short*>(plan->packed);
+        a.packBases = static_cast<const int*>(plan->device);
+        plan->uses += 1;
+        h->planUses += 1;
+    }
+    spgpuPlanUnlock(handle);
+}
+
+template <typename T, int RPL, int PH, bool IS_HELL, int UNROLL, bool STRIPS>
+static void launchSlabPacked(hipStream_t stream, const SlabArgs<T>& a)
+{
+    constexpr int GROUP_ROWS = (kWave / PH) * RPL;
+    constexpr int WAVES = kBlockThreads / kWave;
+    const long long groups = ((long long)a.rows + GROUP_ROWS - 1) / GROUP_ROWS;
+    const unsigned blocks = (unsigned)((groups + WAVES - 1) / WAVES);
+    hipLaunchKernelGGL((slabSpmvKernel<T, RPL, PH, IS_HELL, true, UNROLL, 2, true, 0, STRIPS, kBlockThreads, 0, false, 1, 0, true>),
+                       dim3(blocks), dim3(kBlockThreads), 0, stream, a);
+}
+
 template <typename T, bool IS_HELL>
 static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* prepared = nullptr)
 {
@@ -1439,8 +1667,15 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
         }
         return;
     }
-    if (prepared)
-        return; /* (the forms below learn what they need from their own launches) */
+    if (prepared) {
+        /* (the forms below learn what they need from their own launches) -- Freeze of a matrix without a row order: the default
+         * kernels' 16-bit index copy */
+        if constexpr (WIDE > 1) {
+            if (freeze && !a.rIdx && wideOk && !narrowVariant && !tiled && nt && (variant == 21 || variant == 22) && !deepSplit)
+                *prepared = freezeSlab<T, IS_HELL>(handle, stream, a, variant == 22 ? (kWave / (2 * WIDE)) * WIDE : kWave * WIDE) ? 1 : 0;
+        }
+        return;
+    }
 #ifdef SPGPU_TUNING_VARIANTS
     if (deepSplit) {
         /* shapes in which a lane walks whole rows, for every type; the strip form does not apply to ordered rows */
@@ -1528,10 +1763,18 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
             case 22:
                 if (tiled || autoTile)
                     launchTiled<T, WIDE, IS_HELL, false>(stream, a, tune->xTileShape);
-                else if (strips)
-                    launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true, 0, true>(stream, a, nt);
-                else
-                    launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true>(stream, a, nt);
+                else {
+                    if (nt)
+                        findFrozenSlab(handle, stream, a, (kWave / (2 * WIDE)) * WIDE);
+                    if (a.planPacked && strips)
+                        launchSlabPacked<T, WIDE, 2 * WIDE, IS_HELL, 2, true>(stream, a);
+                    else if (a.planPacked)
+                        launchSlabPacked<T, WIDE, 2 * WIDE, IS_HELL, 2, false>(stream, a);
+                    else if (strips)
+                        launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true, 0, true>(stream, a, nt);
+                    else
+                        launchSlab<T, WIDE, 2 * WIDE, IS_HELL, 2, 2, true>(stream, a, nt);
+                }
                 break;
             default: /* 21 */
                 if (tiled || autoTile)
@@ -1547,10 +1790,18 @@ static void launchSlabFamily(spgpuHandle_t handle, const SlabArgs<T>& in, int* p
                     spgpuNoteSpmvForm(handle, SPGPU_SPMV_FORM_GATHER);
                     a.feedback = nullptr;
                     launchLean<T, WIDE, IS_HELL>(stream, a);
-                } else if (strips)
-                    launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true, 0, true>(stream, a, nt);
-                else
-                    launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true>(stream, a, nt);
+                } else {
+                    if (nt)
+                        findFrozenSlab(handle, stream, a, kWave * WIDE);
+                    if (a.planPacked && strips)
+                        launchSlabPacked<T, WIDE, 1, IS_HELL, 8, true>(stream, a);
+                    else if (a.planPacked)
+                        launchSlabPacked<T, WIDE, 1, IS_HELL, 8, false>(stream, a);
+                    else if (strips)
+                        launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true, 0, true>(stream, a, nt);
+                    else
+                        launchSlab<T, WIDE, 1, IS_HELL, 8, 2, true>(stream, a, nt);
+                }
                 break;
             }
             return;
@@ -1604,6 +1855,8 @@ static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     a.planDeepSubs = nullptr;
     a.planFlags = nullptr;
     a.planDeep = a.planMainBlocks = a.planDeepPerBlock = a.planDeepStride = a.planDeepRuns = 0;
+    a.planPacked = nullptr;
+    a.packBases = nullptr;
     launchSlabFamily<T, true>(handle, a);
     spgpuDebugCheck(handle, "hellspmv");
 }
@@ -1638,6 +1891,8 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
     a.planDeepSubs = nullptr;
     a.planFlags = nullptr;
     a.planDeep = a.planMainBlocks = a.planDeepPerBlock = a.planDeepStride = a.planDeepRuns = 0;
+    a.planPacked = nullptr;
+    a.packBases = nullptr;
     launchSlabFamily<T, false>(handle, a);
     spgpuDebugCheck(handle, "ellspmv");
 }

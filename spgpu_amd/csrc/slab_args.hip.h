@@ -53,6 +53,8 @@ template <typename T> struct SlabArgs {
     int planDeepRuns;                 /* 0: such a workgroup takes sub-groups deepId, deepId + deepBlocks, ... of the list; 1: a run of consecutive ones */
     int planDeepStride;               /* such a workgroup at every planDeepStride-th place of the grid, from the front (0: all of them at the end) */
     int* planFlags;                   /* pinned; [1] = 1: a kernel found the plan contradicting the matrix */
+    const int* packBases;             /* slabSpmvKernel<..., PACKED> (a frozen matrix without a row order): the column the 16-bit words of
+                                       * every group of rows (one wavefront's) count from */
     const unsigned short* planPacked; /* raggedSpmvKernel<..., PACKED>: a frozen matrix' column indices as 16-bit offsets from the block's
                                        * packBase, slot for slot as in rP (0xFFFF: ask rP); NULL: the matrix is not frozen */
 };

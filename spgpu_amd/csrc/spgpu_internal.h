@@ -59,6 +59,7 @@ typedef struct SpgpuPrivateHandle {
     unsigned planClock;
     int planUses, planBuilds, planStales;           /* diagnostics (spgpuSpmvPlanCounts) */
     int planFreezes;                                /* spgpu?SpmvFreeze calls that left a matrix frozen */
+    int planFrozenSlabs;                            /* frozen records of matrices WITHOUT a row order (subs < 0): an SpMV of the default kernels looks one up only when > 0 */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8 /* + one more group of words behind them for spgpu?SpmvForm, and one for the deep list's overflow report */
 #define SPGPU_FEEDBACK_SAMPLES 4
@@ -136,7 +137,8 @@ typedef struct SpgpuSpmvPlan {
     /* key: the arrays the analysis read, and what it assumed */
     const void *rP, *rS, *rIdx, *hackOffsets;
     long long idxStride;
-    int rows, hackSize, baseIndex, maxNnz, deepCap, subs; /* subs: 32-row sub-groups per block */
+    int rows, hackSize, baseIndex, maxNnz, deepCap, subs; /* subs: 32-row sub-groups per block; < 0: the frozen record of a matrix WITHOUT a
+                                                           * row order (ellpack_spmv.hip freezeSlab): -rows per group, `device` = the groups' bases */
     /* state */
     int state;      /* SPGPU_PLAN_EMPTY ... */
     int stales;     /* times it was found stale */
@@ -159,6 +161,8 @@ void spgpuPlanUnlock(spgpuHandle_t h);
 /* Lock held.  The record with this key; or, if there is none, the least recently used record, retired and re-keyed
  * (state EMPTY).  Never NULL once the handle exists (NULL: the handle has no plan table -- its allocation failed). */
 SpgpuSpmvPlan* spgpuPlanRecord(spgpuHandle_t h, const SpgpuSpmvPlan* key);
+/* Lock held.  The record with this key, or NULL (nothing is retired, nothing re-keyed). */
+SpgpuSpmvPlan* spgpuPlanFind(spgpuHandle_t h, const SpgpuSpmvPlan* key);
 /* Lock held.  The plan's device buffer goes to the graveyard (kernels in flight may read it); a full graveyard is emptied
  * after a device-wide wait.  State EMPTY afterwards. */
 void spgpuPlanRetire(spgpuHandle_t h, SpgpuSpmvPlan* plan);

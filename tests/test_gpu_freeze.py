@@ -149,15 +149,13 @@ def test_negative_columns_and_base_index_one(gpu):
 
 
 def test_calls_without_a_packed_form_say_so(gpu):
-    """No row order: no plan, nothing to freeze.  Complex fp64 (16-byte elements: one row per lane, the 2 048-row shape does not
-    exist): a plan, no packed form.  Both stay what they were."""
+    """Complex fp64 (16-byte elements: one row per lane, no 2 048-row shape, no wide slab loads): a plan, no packed form --
+    with and without a row order.  They stay what they were."""
     import torch
     from spgpu_amd import capi, formats, synth
     n = 4 * 2048
-    h = _matrix(gpu, n, "D", 2048, 60, True)
-    code = capi.TYPE_CODE["D"]
-    assert capi.spgpuHellSpmvFreeze(gpu, code, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), None, n, 0) == capi.SPGPU_UNSUPPORTED
     hz = _matrix(gpu, n, "Z", 2048, 60, True)
+    assert capi.spgpuHellSpmvFreeze(gpu, capi.TYPE_CODE["Z"], _dp(hz["cM"]), _dp(hz["rP"]), 32, _dp(hz["hack_offsets"]), _dp(hz["rS"]), None, n, 0) == capi.SPGPU_UNSUPPORTED
     assert _freeze(gpu, "Z", hz, n) == capi.SPGPU_UNSUPPORTED
     assert capi.spgpuSpmvFrozenBytes(gpu) == 0
     x = synth.values_for("Z", 3, n)
@@ -193,4 +191,139 @@ def test_frozen_ell(gpu):
     torch.cuda.synchronize()
     assert capi.plan_counts(gpu)[0] == uses + 1
     assert dz.cpu().numpy().tobytes() == want.tobytes()
+    assert capi.spgpuSpmvThaw(gpu, _dp(dev.rP)) == capi.SPGPU_SUCCESS
+
+
+# ---- matrices WITHOUT a row order: the default kernels' frozen form (ellpack_spmv.hip freezeSlab, slabSpmvKernel<..., PACKED>) ----
+
+def _hell_of(coo, letter, hack=32, base=0):
+    from spgpu_amd import formats
+    n, _, r, c, v = coo
+    ell = formats.coo_to_ell(n, r, c, v, coo_base=base, ell_base=base)
+    return ell, formats.ell_to_hell(ell, hack)
+
+
+def _freeze_plain(gpu, dev):
+    from spgpu_amd import capi
+    return capi.spgpuHellSpmvFreeze(gpu, capi.TYPE_CODE[dev.letter], _dp(dev.cM), _dp(dev.rP), dev.hack_size, _dp(dev.hack_offsets), _dp(dev.rS),
+                                    None, dev.rows, dev.base)
+
+
+def _spmv(gpu, dev, x, y, alpha, beta, avg=0):
+    import torch
+    from spgpu_amd import formats
+    dx = formats.to_device(x)
+    dy = formats.to_device(y) if y is not None else None
+    dz = torch.full((dev.rows,), float("nan"), dtype=dx.dtype, device="cuda")
+    dev.spmv(gpu, dz, dy, alpha, dx, beta, avg)
+    torch.cuda.synchronize()
+    return dz.cpu().numpy()
+
+
+@pytest.mark.parametrize("letter", ["D", "S", "C"])
+@pytest.mark.parametrize("kind", ["band", "band_base1", "near", "ragged_near", "far_escapes"])
+def test_frozen_matrix_without_row_order_same_bits(gpu, letter, kind):
+    """BASELINE configs[1]'s kind of matrix (no rIdx: the default kernels): band columns run the strip form, columns near the row
+    the gather form, ragged lengths the whole-wave tail rows (which read rP itself); `far_escapes`: one entry in 200 lies far
+    away (0xFFFF -> rP).  Frozen == unfrozen == oracle, bit for bit; several calls (AUTO settles on its form on the way)."""
+    from spgpu_amd import capi, formats, synth
+    n = 40 * 128 + 50
+    base = 1 if kind == "band_base1" else 0
+    rng = np.random.default_rng(11)
+    if kind.startswith("band"):
+        coo = synth.banded_coo(n, 16, letter, seed=3, base=base)
+    else:
+        lengths = np.full(n, 24, np.int64) if kind != "ragged_near" else np.minimum(rng.zipf(1.6, size=n) + 3, 400)
+        rows = np.repeat(np.arange(n, dtype=np.int64), lengths)
+        k = np.arange(rows.size, dtype=np.int64) - np.repeat(np.cumsum(lengths) - lengths, lengths)
+        span = np.repeat(np.maximum(lengths * 3, 64), lengths)
+        cols = (rows - span // 2 + (k * span) // np.repeat(lengths, lengths)) % n       # ascending inside a row, within +-span/2
+        if kind == "far_escapes":
+            far = rng.random(rows.size) < 0.005
+            cols = np.where(far, (cols + n // 2 + 70000) % n, cols)
+        coo = (n, n, rows.astype(np.int32), cols.astype(np.int32), synth.values_for(letter, 5, rows.size))
+    ell, hell = _hell_of(coo, letter, base=base)
+    dev = formats.DeviceHell(hell)
+    x, y = synth.values_for(letter, 31, n), synth.values_for(letter, 32, n)
+    want = O.default_spmv(hell, x, y, 1.5, -0.25)
+    for _ in range(3):
+        assert _spmv(gpu, dev, x, y, 1.5, -0.25).tobytes() == want.tobytes()
+    assert _freeze_plain(gpu, dev) == capi.SPGPU_SUCCESS
+    assert capi.spgpuSpmvFrozenBytes(gpu) >= 2 * hell["values"].size
+    uses0 = capi.plan_counts(gpu)[0]
+    for _ in range(4):
+        assert _spmv(gpu, dev, x, y, 1.5, -0.25).tobytes() == want.tobytes()
+    used = capi.plan_counts(gpu)[0] - uses0
+    # every call found the frozen record -- unless AUTO has settled on the LDS-tile form for this matrix (columns inside a window
+    # an LDS tile holds, rows longer than a stage): that form has no packed variant and runs as before
+    assert used == 4 if kind.startswith("band") else used in (0, 4), used
+    want0 = O.default_spmv(hell, x, None, 2.0, 0.0)
+    assert _spmv(gpu, dev, x, None, 2.0, 0.0).tobytes() == want0.tobytes()
+    assert capi.spgpuSpmvThaw(gpu, _dp(dev.rP)) == capi.SPGPU_SUCCESS
+    assert capi.spgpuSpmvFrozenBytes(gpu) == 0
+    uses1 = capi.plan_counts(gpu)[0]
+    assert _spmv(gpu, dev, x, y, 1.5, -0.25).tobytes() == want.tobytes()
+    assert capi.plan_counts(gpu)[0] == uses1
+
+
+@pytest.mark.parametrize("letter", ["D", "S"])
+def test_frozen_gather_form_without_row_order(gpu, letter):
+    """The gather kernel's packed variant, asked for by the handle's form hint (AUTO takes the LDS tile for such columns): columns
+    near the row, ragged lengths (whole-wave tail rows read rP), escapes."""
+    from spgpu_amd import capi, formats, synth
+    n = 30 * 128 + 9
+    rng = np.random.default_rng(3)
+    lengths = np.minimum(rng.zipf(1.7, size=n) + 5, 300)
+    rows = np.repeat(np.arange(n, dtype=np.int64), lengths)
+    k = np.arange(rows.size, dtype=np.int64) - np.repeat(np.cumsum(lengths) - lengths, lengths)
+    span = np.repeat(np.maximum(lengths * 4, 64), lengths)
+    cols = (rows - span // 2 + (k * span) // np.repeat(lengths, lengths)) % n
+    cols = np.where(rng.random(rows.size) < 0.004, (cols + 90000) % n, cols)
+    coo = (n, n, rows.astype(np.int32), cols.astype(np.int32), synth.values_for(letter, 5, rows.size))
+    ell, hell = _hell_of(coo, letter)
+    dev = formats.DeviceHell(hell)
+    x = synth.values_for(letter, 7, n)
+    want = O.default_spmv(hell, x, None, 1.0, 0.0)
+    capi.spgpuSetSpmvForm(gpu, capi.FORM_GATHER)
+    try:
+        assert _spmv(gpu, dev, x, None, 1.0, 0.0).tobytes() == want.tobytes()
+        assert _freeze_plain(gpu, dev) == capi.SPGPU_SUCCESS
+        uses0 = capi.plan_counts(gpu)[0]
+        for _ in range(3):
+            assert _spmv(gpu, dev, x, None, 1.0, 0.0).tobytes() == want.tobytes()
+        assert capi.plan_counts(gpu)[0] - uses0 == 3
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_STRIPS)          # the strip-capable kernel on columns that are no strips
+        assert _spmv(gpu, dev, x, None, 1.0, 0.0).tobytes() == want.tobytes()
+        assert capi.plan_counts(gpu)[0] - uses0 == 4
+    finally:
+        capi.spgpuSetSpmvForm(gpu, capi.FORM_AUTO)
+        capi.spgpuSpmvThaw(gpu, _dp(dev.rP))
+
+
+def test_scattered_matrix_without_row_order_is_not_frozen(gpu):
+    """Columns all over x: more than one entry in a hundred would be an escape -- nothing is frozen, nothing changes."""
+    from spgpu_amd import capi, formats, synth
+    n = 200_000
+    coo = synth.random_rows_coo(n, n, np.full(n, 8), seed=4, letter="D")
+    ell, hell = _hell_of(coo, "D")
+    dev = formats.DeviceHell(hell)
+    assert _freeze_plain(gpu, dev) == capi.SPGPU_UNSUPPORTED
+    assert capi.spgpuSpmvFrozenBytes(gpu) == 0
+    x = synth.values_for("D", 2, n)
+    assert _spmv(gpu, dev, x, None, 1.0, 0.0).tobytes() == O.default_spmv(hell, x, None, 1.0, 0.0).tobytes()
+
+
+def test_frozen_ell_without_row_order(gpu):
+    from spgpu_amd import capi, formats, synth
+    n = 30 * 128 + 7
+    coo = synth.banded_coo(n, 12, "D", seed=9)
+    ell, _ = _hell_of(coo, "D")
+    dev = formats.DeviceEll(ell)
+    x, y = synth.values_for("D", 1, n), synth.values_for("D", 2, n)
+    want = O.default_spmv(ell, x, y, -1.0, 0.5)
+    assert capi.spgpuEllSpmvFreeze(gpu, capi.TYPE_CODE["D"], _dp(dev.cM), _dp(dev.rP), dev.pitch, dev.pitch, _dp(dev.rS), None, dev.max_row, n, 0) == capi.SPGPU_SUCCESS
+    uses0 = capi.plan_counts(gpu)[0]
+    for _ in range(3):
+        assert _spmv(gpu, dev, x, y, -1.0, 0.5).tobytes() == want.tobytes()
+    assert capi.plan_counts(gpu)[0] - uses0 == 3
     assert capi.spgpuSpmvThaw(gpu, _dp(dev.rP)) == capi.SPGPU_SUCCESS
