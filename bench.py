@@ -54,6 +54,9 @@ def parse():
                    help="spmm: who issues a step -- libspgpu.so's sharded driver (RCCL through dlopen), or torch.distributed")
     p.add_argument("--placements", type=int, default=5,
                    help="north_star target: how many placements of the matrix' arrays (allocations of their own, one hipMalloc each) are timed")
+    p.add_argument("--frozen", action="store_true",
+                   help="spmv: the headline matrix is frozen first (spgpuHellSpmvFreeze: 16-bit column indices); the record says so.  "
+                        "Default off: `value` is the plain call; the frozen call is reported beside it as `headline_frozen`")
     p.add_argument("--no-split", action="store_true",
                    help="spmm: do not cut the local block by column ownership (no compute/all-gather overlap)")
     return p.parse_args()
@@ -655,6 +658,10 @@ def run_spmv(args, rank, world):
     z = torch.empty_like(y)
     hacks = h["rows"] // h["hack_size"]
     step = launcher(h, x, y, z, 1.0, 0.0)  # alpha = 1, beta = 0 as the reference's harness (hellPerf.cpp:27-28)
+    if args.frozen:
+        pf = lambda t: C.c_void_p(t.data_ptr())
+        said = capi.spgpuHellSpmvFreeze(handle, capi.TYPE_CODE["D"], pf(h["cM"]), pf(h["rP"]), h["hack_size"], pf(h["hack_offsets"]), pf(h["rS"]), None, h["rows"], 0)
+        assert said == capi.SPGPU_SUCCESS, f"--frozen: spgpuHellSpmvFreeze said {said}"
 
     torch.cuda.synchronize()
     with torch.cuda.stream(stream):
@@ -694,12 +701,13 @@ def run_spmv(args, rank, world):
         steps=args.steps, warmup=args.warmup, ms_per_step=round(wall / args.steps * 1e3, 5),
         higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
         config=dict(workload=f"HELL fp64 SpMV (spgpuDhellspmv), {h['rows']} rows x {args.nnz_per_row} nnz/row uniform, "
-                             f"hackSize 32, columns {args.pattern}, alpha=1 beta=0 (BASELINE configs[1])",
+                             f"hackSize 32, columns {args.pattern}, alpha=1 beta=0 (BASELINE configs[1])"
+                             + (" -- FROZEN first (spgpuHellSpmvFreeze: 16-bit column indices, 10 bytes per nonzero streamed)" if args.frozen else ""),
                     rows=h["rows"], nnz=h["nnz"], hack_size=32, pattern=args.pattern,
                     parallelism="single GPU" if world == 1 else f"{world} independent replicas"),
         roofline=dict(bound="hbm", achieved=round(alg / per_launch * 1e-9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                       frac=round(alg / per_launch * 1e-9 / HBM_PEAK_GBS, 4),
-                      traffic=committed_traffic(h["rows"], args.nnz_per_row, args.pattern),
+                      traffic=None if args.frozen else committed_traffic(h["rows"], args.nnz_per_row, args.pattern),
                       kernel=("sweepSpmvKernel<double, 2 rows x 16 packs per lane, HELL, the default kernel's tail order>: the form "
                               "spgpuGetLastSpmvForm reports: sweep" if headline_form == "sweep" else
                               "slabSpmvKernel<double, RPL 2, 1 phase, HELL, nt, 8 columns/stage, prefetch after gathers, tail> in the form "
@@ -832,6 +840,16 @@ def run_spmv(args, rank, world):
                 types[letter] = dict(ms=round(t * 1e3, 4), hbm_gbs=round(bytes_t / t * 1e-9, 1),
                                      frac=round(bytes_t / t * 1e-9 / HBM_PEAK_GBS, 4), gflops=round(flops_t / t * 1e-9, 1),
                                      parity=spot_check_hell(h, xt, yt, zt, 1.0, 0.0))
+                # frozen (16-bit column indices; complex fp64 has no packed form: SPGPU_UNSUPPORTED)
+                if capi.spgpuHellSpmvFreeze(handle, capi.TYPE_CODE[letter], pt(h["cM"]), pt(h["rP"]), 32, pt(h["hack_offsets"]), pt(h["rS"]), None,
+                                            h["rows"], 0) == capi.SPGPU_SUCCESS:
+                    time_launches(stream, step, 5)
+                    tf = time_launches(stream, step, 50) / 50
+                    zt.zero_()
+                    time_launches(stream, step, 1)
+                    types[letter]["frozen"] = dict(ms=round(tf * 1e3, 4), frac=round(bytes_t / tf * 1e-9 / HBM_PEAK_GBS, 4), gflops=round(flops_t / tf * 1e-9, 1),
+                                                   streamed_bytes_per_nnz=elem + 2, parity=spot_check_hell(h, xt, yt, zt, 1.0, 0.0))
+                    capi.spgpuSpmvThaw(handle, pt(h["rP"]))
                 del xt, yt, zt
             out["other_types_banded"] = types
             # the other BASELINE configurations and the north_star target, each with its oracle check
@@ -871,6 +889,13 @@ def run_spmv(args, rank, world):
                     counted, detail = live_traffic(args)
                 except Exception as error:  # noqa: BLE001 - the record does not depend on the profiler
                     counted, detail = None, repr(error)
+                if counted is not None and isinstance(out.get("headline_frozen"), dict) and "ms" in out["headline_frozen"] and not args.frozen:
+                    try:
+                        counted_f, detail_f = live_traffic(args, extra=("--frozen",))
+                    except Exception as error:  # noqa: BLE001
+                        counted_f, detail_f = None, repr(error)
+                    out["headline_frozen"]["traffic"] = counted_f
+                    out["headline_frozen"]["traffic_source"] = detail_f
                 if counted is not None:
                     out["roofline"]["traffic"] = counted
                     out["roofline"]["traffic_source"] = dict(detail, committed_summary_value=committed,

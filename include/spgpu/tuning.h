@@ -97,14 +97,21 @@ int spgpuEllSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, 
  * (hellPerf.cpp:301-313 is that loop); its index arrays never change in between.  A caller who can PROMISE that -- rP, rS,
  * hackOffsets and rIdx of this matrix stay byte for byte as they are until spgpuSpmvThaw (cM may change at any time: the
  * coefficients are always read from the caller's array) -- lets the library keep what it derives from them: spgpu?SpmvFreeze
- * does what spgpu?SpmvPrepare does and then stores, with the plan, the column indices of the matrix as 16-bit offsets from
- * the first column each block of 1 024 / 2 048 ordered rows reaches (2 bytes per slot of rP; 0xFFFF where a column lies out of
- * that reach: such entries are still read from rP).  Later spgpu?hellspmv / spgpu?ellspmv calls on these arrays -- the same ABI
- * calls, nothing else changes for the caller -- stream 2 bytes of index per stored entry instead of 4: 10 instead of 12 bytes per
- * nonzero in fp64.  Same columns, same x, same order of additions: the bits of z are those of the unfrozen call.
+ * stores the column indices of the matrix as 16-bit offsets (2 bytes per slot of rP; 0xFFFF where a column lies out of reach:
+ * such entries are still read from rP):
+ *   with a row order (rIdx != NULL): what spgpu?SpmvPrepare does, then the copy with the matrix' plan, counted from the first
+ *     column each block of 1 024 / 2 048 ordered rows reaches;
+ *   without one (rIdx == NULL; the default kernels, BASELINE configs[1]): counted from the lowest column of every group of rows
+ *     one wavefront owns (128 rows for the 8-byte types, 32 for fp32); a matrix in which more than one entry in a hundred would
+ *     be out of reach -- scattered columns -- is NOT frozen (its SpMV is bound by the gathers, not by the index stream).
+ * Later spgpu?hellspmv / spgpu?ellspmv calls on these arrays -- the same ABI calls, nothing else changes for the caller -- stream
+ * 2 bytes of index per stored entry instead of 4: 10 instead of 12 bytes per nonzero in fp64, 6 instead of 8 in fp32.  Same
+ * columns, same x, same order of additions: the bits of z are those of the unfrozen call.
  *   SPGPU_SUCCESS      frozen (or already so);
- *   SPGPU_UNSUPPORTED  calls of this kind have no plan or no packed form (no rIdx, complex fp64, the gather form, SPGPU_PLAN=0)
- *                      or there was no memory for the copy: nothing is frozen, nothing wrong.
+ *   SPGPU_UNSUPPORTED  calls of this kind have no packed form (complex fp64; arrays not aligned for 16-byte slab loads; the
+ *                      ordered gather form; SPGPU_PLAN=0; scattered columns without a row order) or there was no memory for
+ *                      the copy: nothing is frozen, nothing wrong.  (The LDS-tile form of the default kernels has no packed
+ *                      variant either: a frozen matrix AUTO runs in that form runs as before.)
  * Breaking the promise gives wrong results for the entries that changed (the library cannot see it: checking would mean
  * reading rP, which is what the copy saves) -- except that a matrix whose row LENGTHS changed is noticed like any stale plan.
  * A frozen plan ends with spgpuSpmvThaw(handle, rP), when it is the least recently used of 8 matrices, or with the handle.
