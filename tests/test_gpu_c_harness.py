@@ -26,6 +26,8 @@ def test_ctest_sequence():
 def test_hellperf_flow(pattern, precision):
     out = _run("hellperf_amd", 200000, 16, pattern, 20, precision)
     assert "checksums identical: PASSED" in out and "OELL checksum equal within rounding: PASSED" in out
+    # the frozen leg (spgpuHellSpmvFreeze from plain C): band columns freeze and give the unfrozen checksum; scattered ones are not frozen
+    assert ("frozen HELL checksum identical: PASSED" in out) == (pattern == "banded")
 
 
 @pytest.mark.parametrize("pattern,precision", [("banded", "s"), ("random", "d")])
