@@ -112,8 +112,10 @@ int spgpuEllSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, 
  *                      ordered gather form; SPGPU_PLAN=0; scattered columns without a row order) or there was no memory for
  *                      the copy: nothing is frozen, nothing wrong.  (The LDS-tile form of the default kernels has no packed
  *                      variant either: a frozen matrix AUTO runs in that form runs as before.)
- * Breaking the promise gives wrong results for the entries that changed (the library cannot see it: checking would mean
- * reading rP, which is what the copy saves) -- except that a matrix whose row LENGTHS changed is noticed like any stale plan.
+ * Breaking the promise is undefined behaviour in the usual sense: wrong results for the entries that changed, and reads of x at
+ * columns the copy never named if rows grew (the library cannot see it: checking would mean reading rP, which is what the copy
+ * saves; an ordered matrix whose row LENGTHS changed is noticed like any stale plan -- by the call that has already used the copy).
+ * Launches captured into a HIP graph never use a frozen copy (a graph outlives a Thaw): they run as unfrozen calls.
  * A frozen plan ends with spgpuSpmvThaw(handle, rP), when it is the least recently used of 8 matrices, or with the handle.
  * spgpuSpmvFrozenBytes: device memory the handle's frozen plans hold.
  */
