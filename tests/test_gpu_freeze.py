@@ -327,3 +327,64 @@ def test_frozen_ell_without_row_order(gpu):
         assert _spmv(gpu, dev, x, y, -1.0, 0.5).tobytes() == want.tobytes()
     assert capi.plan_counts(gpu)[0] - uses0 == 3
     assert capi.spgpuSpmvThaw(gpu, _dp(dev.rP)) == capi.SPGPU_SUCCESS
+
+
+def test_captured_launches_run_unfrozen_and_survive_a_thaw(gpu):
+    """A launch captured into a graph must not carry the frozen copy's address (a graph outlives a Thaw): captured calls run as
+    unfrozen calls -- the record is not used -- and the graph replays with the oracle's bits after the matrix was thawed."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 24 * 128
+    ell, hell = _hell_of(synth.banded_coo(n, 16, "D", seed=3), "D")
+    dev = formats.DeviceHell(hell)
+    assert _freeze_plain(gpu, dev) == capi.SPGPU_SUCCESS
+    dx = formats.to_device(synth.values_for("D", 1, n))
+    dz = torch.zeros(n, dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    capi.spgpuSetStream(gpu, C.c_void_p(side.cuda_stream))
+    torch.cuda.synchronize()
+    try:
+        with torch.cuda.stream(side):
+            dev.spmv(gpu, dz, None, 1.0, dx, 0.0)            # outside the capture: from the frozen record
+        side.synchronize()
+        uses = capi.plan_counts(gpu)[0]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            dev.spmv(gpu, dz, None, 1.0, dx, 0.0)
+        assert capi.plan_counts(gpu)[0] == uses               # the captured launch did not look the record up
+        assert capi.spgpuSpmvThaw(gpu, _dp(dev.rP)) == capi.SPGPU_SUCCESS
+        for rep in range(3):
+            x = synth.values_for("D", 50 + rep, n)
+            dx.copy_(formats.to_device(x))
+            dz.fill_(float("nan"))
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert dz.cpu().numpy().tobytes() == O.default_spmv(hell, x, None, 1.0, 0.0).tobytes(), rep
+    finally:
+        capi.spgpuSetStream(gpu, None)
+
+
+def test_ninth_frozen_matrix_evicts_the_least_recently_used(gpu):
+    """The handle keeps 8 records: a ninth frozen matrix takes the place of the least recently used one, whose calls simply run
+    unfrozen again (same bits); the memory of its copy is given back."""
+    from spgpu_amd import capi, formats, synth
+    n = 16 * 128
+    mats = []
+    for i in range(9):
+        ell, hell = _hell_of(synth.banded_coo(n, 8 + i, "D", seed=20 + i), "D")
+        mats.append((formats.DeviceHell(hell), hell))
+    x = synth.values_for("D", 77, n)
+    for dev, hell in mats:
+        assert _freeze_plain(gpu, dev) == capi.SPGPU_SUCCESS
+        assert _spmv(gpu, dev, x, None, 1.0, 0.0).tobytes() == O.default_spmv(hell, x, None, 1.0, 0.0).tobytes()
+    uses = capi.plan_counts(gpu)[0]
+    dev0, hell0 = mats[0]                                     # the first one has lost its record
+    assert _spmv(gpu, dev0, x, None, 1.0, 0.0).tobytes() == O.default_spmv(hell0, x, None, 1.0, 0.0).tobytes()
+    assert capi.plan_counts(gpu)[0] == uses
+    dev8, hell8 = mats[8]
+    assert _spmv(gpu, dev8, x, None, 1.0, 0.0).tobytes() == O.default_spmv(hell8, x, None, 1.0, 0.0).tobytes()
+    assert capi.plan_counts(gpu)[0] == uses + 1
+    for dev, _ in mats:
+        capi.spgpuSpmvThaw(gpu, _dp(dev.rP))
+    assert capi.spgpuSpmvFrozenBytes(gpu) == 0
