@@ -112,7 +112,7 @@ def live_traffic(args, kernel_words=("SpmvKernel",), extra=()):
                    os.path.abspath(__file__), "--no-extras", "--steps", "10", "--warmup", "2", "--rows", str(args.rows),
                    "--nnz-per-row", str(args.nnz_per_row), "--pattern", args.pattern, *extra]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)
             except subprocess.TimeoutExpired:
                 return None, f"{counter} pass timed out"
             per_kernel = {}
