@@ -2,7 +2,7 @@
 """GPU box: the rocprofv3 artefacts bench.py's roofline block is judged against, written under gpurun_out/profile_<tag>/
 (copy what is to be kept into profiles/).
 
-    python tools/profile_bench.py <tag> spmv|spmm
+    python tools/profile_bench.py <tag> spmv|spmv_frozen|spmm
 
   1. rocprofv3 --kernel-trace --stats -- python3 bench.py ... --no-extras      -> <tag>_bench_<kind>_kernel_stats.csv
   2. rocprofv3 --pmc FETCH_SIZE ... and --pmc WRITE_SIZE ... (separate passes)  -> <tag>_bench_<kind>_pmc.json
@@ -18,8 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, kind = sys.argv[1], sys.argv[2]
 out = os.path.join(ROOT, "gpurun_out", f"profile_{tag}")
 os.makedirs(out, exist_ok=True)
-bench = [os.path.join(ROOT, "bench.py"), "--no-extras"] + (["--workload", "spmm"] if kind == "spmm" else [])
-kernel_key = "hellSpmmStripKernel" if kind == "spmm" else "slabSpmvKernel<double, 2, 1, true, true, 8, 2, true, 0, true"
+bench = [os.path.join(ROOT, "bench.py"), "--no-extras"] + (["--workload", "spmm"] if kind == "spmm" else []) + (["--frozen"] if kind == "spmv_frozen" else [])
+# spmv_frozen: the headline matrix after spgpuHellSpmvFreeze (bench.py --frozen): the PACKED instantiation of the same kernel
+kernel_key = ("hellSpmmStripKernel" if kind == "spmm" else
+              "slabSpmvKernel<double, 2, 1, true, true, 8, 2, true, 0, true, 256, 0, false, 1, 0, true>" if kind == "spmv_frozen" else
+              "slabSpmvKernel<double, 2, 1, true, true, 8, 2, true, 0, true, 256, 0, false, 1, 0, false>")
 env = dict(os.environ, TMPDIR="/tmp")
 
 
@@ -56,7 +59,7 @@ summary = dict(
     workload=dict(rows=rec["config"].get("rows", rec["config"].get("rows_per_gpu")), nnz_per_row=32, pattern=rec["config"]["pattern"],
                   **({"rhs": rec["config"]["rhs"]} if kind == "spmm" else {})),
     command="rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 100 --warmup 10 --no-extras"
-            + (" --workload spmm" if kind == "spmm" else "")
+            + (" --workload spmm" if kind == "spmm" else "") + (" --frozen" if kind == "spmv_frozen" else "")
             + " ; counters in separate runs: --pmc FETCH_SIZE --kernel-trace, --pmc WRITE_SIZE --kernel-trace (--steps 10 --warmup 2)",
     kernel=k["Name"], calls=int(k["Calls"]), average_ns=float(k["AverageNs"]), min_ns=int(k["MinNs"]), max_ns=int(k["MaxNs"]),
     bench_kernel_ms_same_run=rec["roofline"]["kernel_ms"], bench_value_gflops_same_run=rec["value"],

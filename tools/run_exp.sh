@@ -16,6 +16,7 @@ tail -1 gpurun_out/gpu_tests_poison.log
 [ $rc -eq 0 ] || exit 1
 SPGPU_LIB=/root/repo/spgpu_amd/lib_lab/libspgpu.so EXP_LDS_WORD=0xffffffff timeout -k 10 300 python3 tools/stress_lds.py 16 2>&1 | tail -1
 timeout -k 10 800 python3 tools/profile_bench.py $tag spmv 2>&1 | tail -1 || exit 1
+timeout -k 10 600 python3 tools/profile_bench.py $tag spmv_frozen 2>&1 | tail -1 || exit 1
 timeout -k 10 600 python3 tools/profile_bench.py $tag spmm 2>&1 | tail -1 || exit 1
 find gpurun_out/profile_$tag -name "*.csv" -size +3M -delete
 timeout -k 10 900 python3 bench.py > gpurun_out/bench_line.json 2> gpurun_out/bench_err.log || { tail -5 gpurun_out/bench_err.log; exit 1; }
