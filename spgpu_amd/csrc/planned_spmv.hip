@@ -280,7 +280,9 @@ static bool packPlan(SpgpuSpmvPlan* plan, spgpuHandle_t handle, hipStream_t stre
  * the stage size; the chunks of a split sub-group are sized by the unpacked kernels' stage, raggedSplit).  MEASURED with 1
  * (fp64: 4 loads per stage): 36-44 bytes of scratch per lane, and the target goes from 0.68-0.72 to 0.80-0.83 ms (band) -- a
  * spill is re-read behind a vmcnt(0) wait, which drains the prefetch at every item.  Consuming the stage in two halves (8 x values
- * alive instead of 16) leaves the scratch where it is: the ring of three stages is what does not fit.  0 it stays. */
+ * alive instead of 16) leaves the scratch where it is: the ring of three stages is what does not fit.  0 it stays.
+ * Workgroups of 6 wavefronts at 3 per SIMD (168 VGPRs: 4 or 5 loads per stage without scratch) instead: 0.66-0.70 -> 1.01-1.05 ms
+ * on the frozen target -- fewer, longer-lived wavefronts lose more than the deeper stage wins.  Not kept either. */
 #ifndef SPGPU_PACKED_MORE_UNROLL
 #define SPGPU_PACKED_MORE_UNROLL 0
 #endif
