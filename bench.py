@@ -380,12 +380,18 @@ def bench_powerlaw(args, handle, stream, dev, rows):
         # "*_frozen": the same arrays after spgpuHellSpmvFreeze (include/spgpu/tuning.h: the caller promises that the index arrays
         # stay as they are; the library keeps a 16-bit copy of the column indices with the matrix' plan) -- the same ABI call,
         # 10 instead of 12 bytes per nonzero streamed; `frac` is still ALGORITHMIC bytes (12 per nonzero) / time / peak
-        for name, ordered in ({"band": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True), ("sorted_aligned_frozen", True)),
-                               "near": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True), ("sorted_aligned_frozen", True)),
+        # "plain_adopted": the rows as they come, NO rIdx in the call -- after spgpuHellSpmvAdopt (the caller's promise not to touch any of
+        # the matrix' arrays: the library keeps an ordered, frozen copy of its own and runs the call on it; z in the caller's row order)
+        z_aligned = None
+        for name, ordered in ({"band": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True), ("sorted_aligned_frozen", True),
+                                        ("plain_adopted", False)),
+                               "near": (("plain", False), ("sorted_global", True), ("sorted", True), ("sorted_aligned", True), ("sorted_aligned_frozen", True),
+                                        ("plain_adopted", False)),
                                "random": (("plain", False), ("sorted", True))}[pattern]):
             t0 = time.perf_counter()
             window, long_rows = (0, 0) if name == "sorted_global" else (2048, 256)
             frozen = name.endswith("_frozen")
+            adopted = name.endswith("_adopted")
             h = formats.coo_to_ordered_hell_device(handle, rows, *coo, letter, 32, window, long_rows, order=ordered, aligned="aligned" in name)
             build_s = time.perf_counter() - t0
             freeze = lambda a: capi.spgpuHellSpmvFreeze(handle, capi.TYPE_CODE[letter], a["cM"], a["rP"], 32, a["hack_offsets"], a["rS"], a["rIdx"], rows, 0)
@@ -394,6 +400,13 @@ def bench_powerlaw(args, handle, stream, dev, rows):
                 said = freeze({k: p(h[k]) for k in ("cM", "rP", "hack_offsets", "rS", "rIdx")})
                 torch.cuda.synchronize()
                 freeze_s, frozen_bytes = time.perf_counter() - t0, capi.spgpuSpmvFrozenBytes(handle)
+                assert said == capi.SPGPU_SUCCESS, said
+            adopt = lambda a: capi.spgpuHellSpmvAdopt(handle, capi.TYPE_CODE[letter], a["cM"], a["rP"], 32, a["hack_offsets"], a["rS"], rows, 0)
+            if adopted:
+                t0 = time.perf_counter()
+                said = adopt({k: p(h[k]) for k in ("cM", "rP", "hack_offsets", "rS")})
+                torch.cuda.synchronize()
+                adopt_s, adopted_bytes = time.perf_counter() - t0, capi.spgpuSpmvFrozenBytes(handle)
                 assert said == capi.SPGPU_SUCCESS, said
             # form AUTO throughout: through rIdx the tile form falls back to gathers column by column, and on scattered
             # columns it runs within 1 % of the plain gather form (tools/exp_tile.py, ragged0 vs raggedg)
@@ -405,20 +418,25 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             as_built = [time_launches(stream, call, 20) / 20 * 1e3 for _ in range(3)]
             t = sorted(as_built)[1] * 1e-3
             placements = None
-            if ordered and pattern != "random" and name != "sorted_global" and args.placements > 0:
+            if (ordered or adopted) and pattern != "random" and name != "sorted_global" and args.placements > 0:
                 placements = []
                 for _ in range(args.placements):
-                    own = OwnAllocations(dict(cM=h["cM"], rP=h["rP"], hack_offsets=h["hack_offsets"], rS=h["rS"], rIdx=h["rIdx"], x=x, z=z))
+                    arrays = dict(cM=h["cM"], rP=h["rP"], hack_offsets=h["hack_offsets"], rS=h["rS"], x=x, z=z)
+                    if h["rIdx"] is not None:
+                        arrays["rIdx"] = h["rIdx"]
+                    own = OwnAllocations(arrays)
                     try:
                         torch.cuda.synchronize()
                         if frozen:
                             assert freeze(own) == capi.SPGPU_SUCCESS
+                        if adopted:
+                            assert adopt(own) == capi.SPGPU_SUCCESS
                         placed = lambda own=own: capi.hellspmv[letter](handle, own["z"], None, C.c_double(1.0), own["cM"], own["rP"], 32, own["hack_offsets"],
-                                                                       own["rS"], own["rIdx"], 32, rows, own["x"], C.c_double(0.0), 0)
+                                                                       own["rS"], own.ptr.get("rIdx"), 32, rows, own["x"], C.c_double(0.0), 0)
                         placements.append(timed_blocks(stream, placed))
                     finally:
                         torch.cuda.synchronize()
-                        if frozen:
+                        if frozen or adopted:
                             capi.spgpuSpmvThaw(handle, own["rP"])
                         own.free()
                 t = sorted(sorted(blocks)[len(blocks) // 2] for blocks in placements)[len(placements) // 2] * 1e-3
@@ -430,11 +448,18 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             hacks = (rows + 31) // 32
             alg = h["nnz"] * (elem + 4) + rows * (4 + elem) + rows * elem + hacks * 4 + (rows * 4 if ordered else 0)
             shape = O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP) if ordered else O.slab_shape(letter)
+            if name == "sorted_aligned":
+                z_aligned = z.clone()
+            if adopted:   # z in the caller's row order, the ordered kernel's sums: the explicitly ordered call's bits
+                same = z_aligned is not None and bool(torch.equal(z.view(torch.int64), z_aligned.view(torch.int64)))
+                adopted_parity = ("bit-identical to the explicitly ordered call (sorted_aligned), itself " + out[f"{pattern}_sorted_aligned"]["parity"]) if same \
+                    else "MISMATCH vs the explicitly ordered call"
             out[f"{pattern}_{name}"] = dict(slots_per_nnz=round(h["slots"] / h["nnz"], 3), ms=round(t * 1e3, 4),
                                             gflops=round(2.0 * h["nnz"] / t * 1e-9, 1), hbm_gbs=round(alg / t * 1e-9, 1),
                                             frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4), algorithmic_bytes=alg,
                                             hell_GB=round(h["slots"] * (elem + 4) * 1e-9, 2), build_ms=round(build_s * 1e3, 1), form=ran,
-                                            parity=check_windows(h, x, z, letter, shape), as_built_ms=[round(v, 4) for v in as_built])
+                                            parity=adopted_parity if adopted else check_windows(h, x, z, letter, shape),
+                                            as_built_ms=[round(v, 4) for v in as_built])
             if placements:
                 entry = out[f"{pattern}_{name}"]
                 entry["placements_ms"] = [[round(v, 4) for v in blocks] for blocks in placements]
@@ -444,6 +469,13 @@ def bench_powerlaw(args, handle, stream, dev, rows):
             if ordered:
                 entry = out[f"{pattern}_{name}"]
                 entry["plan_counts_uses_builds_stales"] = list(capi.plan_counts(handle))
+            if adopted:
+                entry = out[f"{pattern}_{name}"]
+                entry["adopt_ms"] = round(adopt_s * 1e3, 1)
+                entry["adopted_copy_GB"] = round(adopted_bytes * 1e-9, 3)
+                entry["calls_on_the_copy"] = capi.spgpuSpmvAdoptedUses(handle)
+                entry["slots_per_nnz_of_the_copy"] = out[f"{pattern}_sorted_aligned"]["slots_per_nnz"]
+                capi.spgpuSpmvThaw(handle, p(h["rP"]))
             if frozen:
                 entry = out[f"{pattern}_{name}"]
                 entry["freeze_ms"] = round(freeze_s * 1e3, 1)
@@ -870,12 +902,14 @@ def run_spmv(args, rank, world):
             pl = configs.get("powerlaw_fp64", {})
             target = {name: {key: pl[name][key] for key in ("ms", "frac", "frac_spread", "ms_spread", "slots_per_nnz", "streamed_bytes_per_nnz", "parity") if key in pl[name]}
                       for name in ("band_sorted_aligned", "band_sorted_aligned_frozen", "band_sorted", "near_sorted_aligned", "near_sorted_aligned_frozen",
-                                   "near_sorted", "band_sorted_global", "band_plain", "near_plain")
+                                   "near_sorted", "band_sorted_global", "band_plain", "band_plain_adopted", "near_plain", "near_plain_adopted")
                       if isinstance(pl.get(name), dict)}
             target["what"] = ("north_star target: spgpuDhellspmv, fp64, 10 M rows, power-law lengths (mean 32, max 2048), rows ordered "
                               "on the device (windows of 2048, rows > 256 set aside) and run through rIdx; *_aligned: the order whose windows "
                               "coincide with the kernel's 2048-row workgroups (spgpuOellOrderAlignedDevice); *_global: the reference's own order, "
-                              "one sort of all rows (ellToOell, ell.c:85-202); *_plain: the rows as they come, no rIdx; *_frozen: the same arrays and the same "
+                              "one sort of all rows (ellToOell, ell.c:85-202); *_plain: the rows as they come, no rIdx; *_plain_adopted: the same arrays and the same call WITHOUT rIdx after "
+                              "spgpuHellSpmvAdopt (the caller's promise not to touch the matrix: the library orders and freezes a copy of its own and runs the "
+                              "call on it; z in the caller's row order, the explicitly ordered call's bits); *_frozen: the same arrays and the same "
                               "spgpuDhellspmv call after spgpuHellSpmvFreeze (the caller's promise that the index arrays stay as they are: the library "
                               "streams its 16-bit copy of the column indices, 10 instead of 12 bytes per nonzero; bit-identical results); frac = "
                               "algorithmic bytes (12 per nonzero, frozen or not) / time / 8 TB/s, time = median over placements of the arrays (ms_spread / frac_spread: every timed block); bar 0.70")

@@ -126,6 +126,24 @@ int spgpuEllSpmvFreeze(spgpuHandle_t handle, spgpuType_t type, const void* cM, c
 int spgpuSpmvThaw(spgpuHandle_t handle, const int* rP);
 long long spgpuSpmvFrozenBytes(spgpuHandle_t handle);
 
+/*
+ * ADOPTED matrices (no counterpart in the reference; csrc/adopted_hell.hip).  A HELL matrix with very unequal row lengths stores
+ * several slots per nonzero when its rows come as they are (4.99 on the north_star target), and any kernel that takes it as it
+ * is pays for them; the reference's remedy is the caller's -- order the rows by length and pass the permutation as rIdx
+ * (ellToOell, hellPerf.cpp:324-378).  spgpuHellSpmvAdopt does that FOR a caller who promises more than Freeze asks: NONE of the
+ * matrix' arrays -- cM, rP, rS, hackOffsets -- changes until spgpuSpmvThaw(handle, rP).  The library then keeps its own copy of
+ * the matrix with the rows in spgpuOellOrderAlignedDevice's order (windows of 2 048, rows longer than 256 set aside), frozen;
+ * spgpu?hellspmv calls on the caller's arrays with rIdx == NULL run on that copy and write z through its row order: z[i] for
+ * the caller's row i, as ever, the value the ordered kernel computes (equal to the plain kernel's within rounding; bit for bit
+ * what the caller would get by ordering the matrix himself with the same device calls).  Cost: device memory for the ordered
+ * matrix (spgpuSpmvFrozenBytes counts it) and ~10-30 ms once.  SPGPU_UNSUPPORTED: hackSize not a multiple of 32, no memory, or
+ * four matrices adopted already.  Launches captured into a HIP graph run on the caller's arrays.
+ * spgpuSpmvAdoptedUses: calls that ran on a copy.
+ */
+int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,
+                       int rows, int baseIndex);
+int spgpuSpmvAdoptedUses(spgpuHandle_t handle);
+
 void spgpuTuningReload(void);
 /* 1 if the library was built with -DSPGPU_TUNING_VARIANTS: the non-default kernel shapes (SPGPU_SPMV_VARIANT, SPGPU_X_TILE_SHAPE,
  * SPGPU_RAGGED_SHAPE, SPGPU_RAGGED=0) exist only in such a build; the product build carries the defaults and ignores those knobs. */

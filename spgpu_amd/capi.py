@@ -262,6 +262,8 @@ spgpuSpmvPlanCounts = _decl("spgpuSpmvPlanCounts", None, [Handle, C.POINTER(i32)
 spgpuHellSpmvPrepare = _decl("spgpuHellSpmvPrepare", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, ptr, i32, i32])
 spgpuHellSpmvFreeze = _decl("spgpuHellSpmvFreeze", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, ptr, i32, i32])
 spgpuEllSpmvFreeze = _decl("spgpuEllSpmvFreeze", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, ptr, i32, i32, i32])
+spgpuHellSpmvAdopt = _decl("spgpuHellSpmvAdopt", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, i32, i32])
+spgpuSpmvAdoptedUses = _decl("spgpuSpmvAdoptedUses", i32, [Handle])
 spgpuSpmvThaw = _decl("spgpuSpmvThaw", i32, [Handle, ptr])
 spgpuSpmvFrozenBytes = _decl("spgpuSpmvFrozenBytes", C.c_longlong, [Handle])
 spgpuEllSpmvPrepare = _decl("spgpuEllSpmvPrepare", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, ptr, i32, i32, i32])

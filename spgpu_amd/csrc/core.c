@@ -132,6 +132,7 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     h->spmvForm = SPGPU_SPMV_FORM_AUTO;
     hipSetDevice(device);
     deepListFor(h, h->pub.defaultStream); /* failing that, ordered matrices run the kernel that needs no list */
+    h->adopted = (SpgpuAdopted*)calloc(SPGPU_ADOPTED, sizeof(SpgpuAdopted)); /* failing this, nothing can be adopted */
     /* the plan table (spgpu_internal.h): failing this, ordered matrices run without plans */
     h->plans = (SpgpuSpmvPlan*)calloc(SPGPU_PLANS, sizeof(SpgpuSpmvPlan));
     if (h->plans && hipHostMalloc((void**)&h->planPinned, SPGPU_PLANS * SPGPU_PLAN_WORDS * sizeof(int), hipHostMallocDefault) == hipSuccess) {
@@ -152,6 +153,8 @@ spgpuStatus_t spgpuCreate(spgpuHandle_t* pHandle, int device)
     return SPGPU_SUCCESS;
 }
 
+static void freeAdopted(const SpgpuAdopted* e);
+
 void spgpuDestroy(spgpuHandle_t pHandle)
 {
     if (!pHandle)
@@ -168,6 +171,12 @@ void spgpuDestroy(spgpuHandle_t pHandle)
     for (int i = 0; i < h->deepStreams; ++i) {
         hipFree(h->deepScratch[i]);
         hipEventDestroy(h->deepIdle[i]);
+    }
+    if (h->adopted) {
+        for (int i = 0; i < SPGPU_ADOPTED; ++i)
+            if (h->adopted[i].rows > 0)
+                freeAdopted(&h->adopted[i]);
+        free(h->adopted);
     }
     if (h->plans) {
         for (int i = 0; i < SPGPU_PLANS; ++i) {
@@ -451,14 +460,109 @@ void spgpuSpmvPlanCounts(spgpuHandle_t pHandle, int* uses, int* builds, int* sta
     pthread_mutex_unlock(&h->formLock);
 }
 
+/* ---- adopted matrices (spgpu_internal.h, csrc/adopted_hell.hip) ---- */
+const SpgpuAdopted* spgpuAdoptedFind(spgpuHandle_t pHandle, hipStream_t stream, const void* cM, const int* rP, const int* rS,
+                                     const int* hackOffsets, int rows, int hackSize, int baseIndex)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    if (!h->adopted || __atomic_load_n(&h->adoptedCount, __ATOMIC_RELAXED) <= 0)
+        return NULL;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return NULL;
+    }
+    const SpgpuAdopted* found = NULL;
+    pthread_mutex_lock(&h->formLock);
+    for (int i = 0; i < SPGPU_ADOPTED; ++i) {
+        const SpgpuAdopted* e = &h->adopted[i];
+        if (e->rows > 0 && e->rP == (const void*)rP && e->cM == cM && e->rS == (const void*)rS && e->hackOffsets == (const void*)hackOffsets &&
+            e->rows == rows && e->hackSize == hackSize && e->baseIndex == baseIndex) {
+            found = e;
+            h->adoptedUses += 1;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&h->formLock);
+    return found; /* (an entry's arrays live until spgpuSpmvThaw, which the caller may not run beside an SpMV on the same matrix) */
+}
+
+int spgpuAdoptedAdd(spgpuHandle_t pHandle, const SpgpuAdopted* entry)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    int said = SPGPU_UNSUPPORTED;
+    if (!h->adopted)
+        return said;
+    pthread_mutex_lock(&h->formLock);
+    for (int i = 0; i < SPGPU_ADOPTED; ++i) {
+        if (h->adopted[i].rows == 0) {
+            h->adopted[i] = *entry;
+            h->adoptedCount += 1;
+            said = SPGPU_SUCCESS;
+            break;
+        }
+    }
+    pthread_mutex_unlock(&h->formLock);
+    return said;
+}
+
+int spgpuAdoptedRemove(spgpuHandle_t pHandle, const int* rP, SpgpuAdopted* out)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    int n = 0;
+    if (!h->adopted)
+        return 0;
+    pthread_mutex_lock(&h->formLock);
+    for (int i = 0; i < SPGPU_ADOPTED; ++i) {
+        if (h->adopted[i].rows > 0 && (rP == NULL || h->adopted[i].rP == (const void*)rP)) {
+            out[n++] = h->adopted[i];
+            memset(&h->adopted[i], 0, sizeof(SpgpuAdopted));
+            h->adoptedCount -= 1;
+        }
+    }
+    pthread_mutex_unlock(&h->formLock);
+    return n;
+}
+
+int spgpuSpmvAdoptedUses(spgpuHandle_t pHandle)
+{
+    SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
+    pthread_mutex_lock(&h->formLock);
+    const int n = h->adoptedUses;
+    pthread_mutex_unlock(&h->formLock);
+    return n;
+}
+
 /* spgpu?SpmvFreeze's counterpart (include/spgpu/tuning.h): the plans of the matrix with this index array lose their 16-bit copies
  * -- retired whole, the next SpMV analyses the matrix again. */
+static void freeAdopted(const SpgpuAdopted* e)
+{
+    hipFree(e->values);
+    hipFree(e->indices);
+    hipFree(e->hackOffsetsOrdered);
+    hipFree(e->lengths);
+    hipFree(e->order);
+}
+
 int spgpuSpmvThaw(spgpuHandle_t pHandle, const int* rP)
 {
     SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
     int thawed = 0;
     if (!h || !h->plans || !rP)
         return SPGPU_UNSPECIFIED;
+    {
+        /* an adopted matrix: the plan of its ordered copy goes first (keyed by the copy's arrays), then the copy -- behind a
+         * device-wide wait: SpMVs in flight read it */
+        SpgpuAdopted gone[SPGPU_ADOPTED];
+        const int n = spgpuAdoptedRemove(pHandle, rP, gone);
+        if (n > 0)
+            hipDeviceSynchronize();
+        for (int i = 0; i < n; ++i) {
+            (void)spgpuSpmvThaw(pHandle, gone[i].indices);
+            freeAdopted(&gone[i]);
+            thawed += 1;
+        }
+    }
     pthread_mutex_lock(&h->formLock);
     for (int i = 0; i < SPGPU_PLANS; ++i) {
         SpgpuSpmvPlan* p = &h->plans[i];
@@ -481,6 +585,8 @@ long long spgpuSpmvFrozenBytes(spgpuHandle_t pHandle)
     if (!h || !h->plans)
         return 0;
     pthread_mutex_lock(&h->formLock);
+    for (int i = 0; h->adopted && i < SPGPU_ADOPTED; ++i)
+        bytes += h->adopted[i].rows > 0 ? h->adopted[i].bytes : 0;
     for (int i = 0; i < SPGPU_PLANS; ++i)
         bytes += h->plans[i].packed ? h->plans[i].packedBytes : 0;
     pthread_mutex_unlock(&h->formLock);

@@ -1831,6 +1831,17 @@ static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
                      const ApiT* x, ApiT beta, int baseIndex, int avgNnzPerRow = 0)
 {
     static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
+    /* an ADOPTED matrix (spgpuHellSpmvAdopt, adopted_hell.hip): the call runs on the library's ordered copy and writes z through the
+     * copy's row order -- z in the caller's row order, as ever */
+    if (!rIdx) {
+        if (const SpgpuAdopted* copy = spgpuAdoptedFind(handle, handle->currentStream, cM, rP, rS, hackOffsets, rows, hackSize, baseIndex)) {
+            cM = static_cast<const ApiT*>(copy->values);
+            rP = copy->indices;
+            hackOffsets = copy->hackOffsetsOrdered;
+            rS = copy->lengths;
+            rIdx = copy->order;
+        }
+    }
     SlabArgs<T> a;
     a.z = reinterpret_cast<T*>(z);
     a.y = reinterpret_cast<const T*>(y);

@@ -59,6 +59,11 @@ typedef struct SpgpuPrivateHandle {
     unsigned planClock;
     int planUses, planBuilds, planStales;           /* diagnostics (spgpuSpmvPlanCounts) */
     int planFreezes;                                /* spgpu?SpmvFreeze calls that left a matrix frozen */
+    /* ADOPTED matrices (spgpuHellSpmvAdopt, include/spgpu/tuning.h; csrc/adopted_hell.hip): a HELL matrix without a row order whose rows
+     * are ragged, of which the library keeps its own copy with the rows ordered by length; guarded by formLock */
+    struct SpgpuAdopted* adopted;                   /* [SPGPU_ADOPTED] */
+    int adoptedCount;                               /* entries in use: an SpMV without rIdx looks one up only when > 0 */
+    int adoptedUses;
     int planFrozenSlabs;                            /* frozen records of matrices WITHOUT a row order (subs < 0): an SpMV of the default kernels looks one up only when > 0 */
 } SpgpuPrivateHandle;
 #define SPGPU_FEEDBACK_ENTRIES 8 /* + one more group of words behind them for spgpu?SpmvForm, and one for the deep list's overflow report */
@@ -163,6 +168,26 @@ void spgpuPlanUnlock(spgpuHandle_t h);
 SpgpuSpmvPlan* spgpuPlanRecord(spgpuHandle_t h, const SpgpuSpmvPlan* key);
 /* Lock held.  The record with this key, or NULL (nothing is retired, nothing re-keyed). */
 SpgpuSpmvPlan* spgpuPlanFind(spgpuHandle_t h, const SpgpuSpmvPlan* key);
+/* An adopted matrix: the caller's arrays (the key) and the library's ordered copy of them. */
+#define SPGPU_ADOPTED 4
+typedef struct SpgpuAdopted {
+    const void *cM, *rP, *rS, *hackOffsets; /* the caller's (key; rows == 0: free entry) */
+    int rows, hackSize, baseIndex, type;
+    void* values;       /* ordered copy: coefficients */
+    int* indices;       /* column indices */
+    int* hackOffsetsOrdered;
+    int* lengths;       /* row lengths in the new order */
+    int* order;         /* rIdx: original row of every position */
+    long long bytes;    /* device memory of the copy */
+} SpgpuAdopted;
+/* No lock held.  The ordered copy of these arrays, or NULL (none, or the stream is capturing: a graph would outlive the copy). */
+const SpgpuAdopted* spgpuAdoptedFind(spgpuHandle_t h, hipStream_t stream, const void* cM, const int* rP, const int* rS, const int* hackOffsets,
+                                     int rows, int hackSize, int baseIndex);
+/* No lock held.  Takes a free entry for `entry` (copied); SPGPU_UNSUPPORTED when the table is full. */
+int spgpuAdoptedAdd(spgpuHandle_t h, const SpgpuAdopted* entry);
+/* No lock held.  Removes the entries keyed by rP (NULL: all); their arrays are returned in `out` (at most SPGPU_ADOPTED) for the caller to free. */
+int spgpuAdoptedRemove(spgpuHandle_t h, const int* rP, SpgpuAdopted* out);
+
 /* Lock held.  The plan's device buffer goes to the graveyard (kernels in flight may read it); a full graveyard is emptied
  * after a device-wide wait.  State EMPTY afterwards. */
 void spgpuPlanRetire(spgpuHandle_t h, SpgpuSpmvPlan* plan);

@@ -7,11 +7,11 @@ mkdir -p gpurun_out
 timeout -k 10 1100 python3 -m pytest tests -q -m gpu -x > gpurun_out/gpu_tests.log 2>&1; rc=$?
 tail -4 gpurun_out/gpu_tests.log
 [ $rc -eq 0 ] || exit 1
-SPGPU_LIB=/root/repo/spgpu_amd/lib_lab/libspgpu.so timeout -k 10 1100 python3 -m pytest tests/test_gpu_oell_device.py tests/test_gpu_spmv.py tests/test_gpu_share.py tests/test_gpu_spmm.py tests/test_gpu_plan.py tests/test_gpu_fuzz.py tests/test_gpu_padding.py tests/test_gpu_freeze.py -q -m gpu -x > gpurun_out/gpu_tests_lab.log 2>&1; rc=$?
+SPGPU_LIB=/root/repo/spgpu_amd/lib_lab/libspgpu.so timeout -k 10 1100 python3 -m pytest tests/test_gpu_oell_device.py tests/test_gpu_spmv.py tests/test_gpu_share.py tests/test_gpu_spmm.py tests/test_gpu_plan.py tests/test_gpu_fuzz.py tests/test_gpu_padding.py tests/test_gpu_freeze.py tests/test_gpu_adopt.py -q -m gpu -x > gpurun_out/gpu_tests_lab.log 2>&1; rc=$?
 tail -3 gpurun_out/gpu_tests_lab.log
 [ $rc -eq 0 ] || exit 1
 # the ordered paths once more with the library's uninitialised scratch filled with 0xFF, and with the LDS of every CU filled with -1 / NaN in front of every call
-SPGPU_POISON_SCRATCH=1 timeout -k 10 600 python3 -m pytest tests/test_gpu_plan.py tests/test_gpu_oell_device.py tests/test_gpu_padding.py tests/test_gpu_freeze.py -q -m gpu -x > gpurun_out/gpu_tests_poison.log 2>&1; rc=$?
+SPGPU_POISON_SCRATCH=1 timeout -k 10 600 python3 -m pytest tests/test_gpu_plan.py tests/test_gpu_oell_device.py tests/test_gpu_padding.py tests/test_gpu_freeze.py tests/test_gpu_adopt.py -q -m gpu -x > gpurun_out/gpu_tests_poison.log 2>&1; rc=$?
 tail -1 gpurun_out/gpu_tests_poison.log
 [ $rc -eq 0 ] || exit 1
 SPGPU_LIB=/root/repo/spgpu_amd/lib_lab/libspgpu.so EXP_LDS_WORD=0xffffffff timeout -k 10 300 python3 tools/stress_lds.py 16 2>&1 | tail -1
