@@ -136,7 +136,7 @@ long long spgpuSpmvFrozenBytes(spgpuHandle_t handle);
  * spgpu?hellspmv calls on the caller's arrays with rIdx == NULL run on that copy and write z through its row order: z[i] for
  * the caller's row i, as ever, the value the ordered kernel computes (equal to the plain kernel's within rounding; bit for bit
  * what the caller would get by ordering the matrix himself with the same device calls).  Cost: device memory for the ordered
- * matrix (spgpuSpmvFrozenBytes counts it) and ~10-30 ms once.  SPGPU_UNSUPPORTED: hackSize not a multiple of 32, no memory, or
+ * matrix (spgpuSpmvFrozenBytes counts it) and ~17 ms once for the 10 M-row target.  SPGPU_UNSUPPORTED: hackSize not a multiple of 32, no memory, or
  * four matrices adopted already.  Launches captured into a HIP graph run on the caller's arrays.
  * spgpuSpmvAdoptedUses: calls that ran on a copy.
  */
