@@ -104,6 +104,8 @@ int spgpuEllSpmvPrepare(spgpuHandle_t handle, spgpuType_t type, const void* cM, 
  *   without one (rIdx == NULL; the default kernels, BASELINE configs[1]): counted from the lowest column of every group of rows
  *     one wavefront owns (128 rows for the 8-byte types, 32 for fp32); a matrix in which more than one entry in a hundred would
  *     be out of reach -- scattered columns -- is NOT frozen (its SpMV is bound by the gathers, not by the index stream).
+ * The same rule holds with a row order: more than one escape in a hundred entries and the matrix keeps its plan but gets no copy
+ * (SPGPU_UNSUPPORTED; SPGPU_FREEZE_MAX_ESCAPES_PCT, default 1, is the knob -- 100 freezes anything).
  * Later spgpu?hellspmv / spgpu?ellspmv calls on these arrays -- the same ABI calls, nothing else changes for the caller -- stream
  * 2 bytes of index per stored entry instead of 4: 10 instead of 12 bytes per nonzero in fp64, 6 instead of 8 in fp32.  Same
  * columns, same x, same order of additions: the bits of z are those of the unfrozen call.

@@ -656,6 +656,7 @@ void spgpuTuningReload(void)
     t.planDeepSpread = envInt("SPGPU_PLAN_DEEP_SPREAD", 60);
     t.planDeepPerBlock = envInt("SPGPU_PLAN_DEEP_PER_BLOCK", 8);
     t.planDeepRuns = envInt("SPGPU_PLAN_DEEP_RUNS", 1);
+    t.freezeEscapesPct = envInt("SPGPU_FREEZE_MAX_ESCAPES_PCT", 1);
     t.stageLate = envInt("SPGPU_STAGE_LATE", 1);
     tuning = t;
     __atomic_store_n(&tuningLoaded, 1, __ATOMIC_RELEASE);

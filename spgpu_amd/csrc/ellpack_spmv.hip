@@ -1407,7 +1407,8 @@ static bool freezeSlab(spgpuHandle_t handle, hipStream_t stream, const SlabArgs<
                                a.idxStride, a.maxNnz, a.rows, a.baseIndex, groupRows, static_cast<int*>(device), static_cast<unsigned short*>(packed), counts);
             ok = hipMemcpyAsync(said, counts, sizeof(said), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
         }
-        if (ok && said[1] * 100ull <= said[0]) { /* at most one escape in a hundred entries */
+        const int mostPct = spgpuTuning()->freezeEscapesPct < 0 ? 0 : spgpuTuning()->freezeEscapesPct;
+        if (ok && said[1] * 100ull <= said[0] * (unsigned long long)mostPct) { /* at most one escape in a hundred entries (SPGPU_FREEZE_MAX_ESCAPES_PCT) */
             plan->device = device;
             plan->packed = packed;
             plan->packedBytes = (long long)packedBytes;

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kWave) void planSlotsKernel(const int* __restrict__
 template <bool IS_HELL, int SUBS>
 __global__ __launch_bounds__(256) void planPackKernel(const int* __restrict__ rP, const int* __restrict__ rS, const int* __restrict__ hackOffsets,
                                                      int hackSize, long long idxStride, int maxNnz, int rows, int baseIndex,
-                                                     SpgpuPlanBlock* blocks, unsigned short* __restrict__ packed)
+                                                     SpgpuPlanBlock* blocks, unsigned short* __restrict__ packed, unsigned long long* counts)
 {
     constexpr int BLOCK = 256, ROWS = SUBS * 32, RPT = ROWS / BLOCK;
     const SpgpuPlanBlock record = blocks[blockIdx.x]; /* (workgroup-uniform) */
@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void planPackKernel(const int* __restrict__ rP
     if (threadIdx.x == 0)
         blocks[blockIdx.x].packBase = packBase;
     const long long blockRow0 = (long long)blockIdx.x * ROWS;
+    unsigned entries = 0, escapes = 0; /* counts[0], counts[1]: the host keeps the copy only if few entries are escapes */
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
         const int i = threadIdx.x + j * BLOCK;
@@ -217,8 +218,17 @@ __global__ __launch_bounds__(256) void planPackKernel(const int* __restrict__ rP
         for (int k = 0; k < len; ++k, at += idxStride) {
             const int col = rP[at] - baseIndex;
             const long long off = (long long)col - packBase;
-            packed[at] = col >= 0 && off >= 0 && off < 0xFFFF ? (unsigned short)off : (unsigned short)0xFFFF;
+            const bool fits = col >= 0 && off >= 0 && off < 0xFFFF;
+            packed[at] = fits ? (unsigned short)off : (unsigned short)0xFFFF;
+            entries += 1;
+            escapes += fits ? 0 : 1;
         }
+    }
+    entries = (unsigned)waveReduce((int)entries, SumOf{});
+    escapes = (unsigned)waveReduce((int)escapes, SumOf{});
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        atomicAdd(&counts[0], (unsigned long long)entries);
+        atomicAdd(&counts[1], (unsigned long long)escapes);
     }
 }
 
@@ -242,7 +252,7 @@ static bool packPlan(SpgpuSpmvPlan* plan, spgpuHandle_t handle, hipStream_t stre
     }
     if (slots <= 0)
         return false;
-    const size_t bytes = ((size_t)slots * sizeof(unsigned short) + 255) / 256 * 256; /* (a lane's last pack may reach past the last real slot's word) */
+    const size_t bytes = ((size_t)slots * sizeof(unsigned short) + 255) / 256 * 256 + 256; /* (a lane's last pack may reach past the last real slot's word; + the two counters) */
     void* packed = nullptr;
     int previous = 0;
     (void)hipGetDevice(&previous);
@@ -257,13 +267,23 @@ static bool packPlan(SpgpuSpmvPlan* plan, spgpuHandle_t handle, hipStream_t stre
         (void)hipMemsetAsync(packed, 0xA5, bytes, stream);
     SpgpuPlanBlock* records = static_cast<SpgpuPlanBlock*>(plan->device);
     unsigned short* words = static_cast<unsigned short*>(packed);
+    unsigned long long* counts = reinterpret_cast<unsigned long long*>(static_cast<char*>(packed) + bytes - 256);
+    (void)hipMemsetAsync(counts, 0, 2 * sizeof(unsigned long long), stream);
     if (plan->subs == 64)
         hipLaunchKernelGGL((planPackKernel<IS_HELL, 64>), dim3((unsigned)plan->blocks), dim3(256), 0, stream, rP, rS, hackOffsets, plan->hackSize,
-                           plan->idxStride, plan->maxNnz, plan->rows, plan->baseIndex, records, words);
+                           plan->idxStride, plan->maxNnz, plan->rows, plan->baseIndex, records, words, counts);
     else
         hipLaunchKernelGGL((planPackKernel<IS_HELL, 32>), dim3((unsigned)plan->blocks), dim3(256), 0, stream, rP, rS, hackOffsets, plan->hackSize,
-                           plan->idxStride, plan->maxNnz, plan->rows, plan->baseIndex, records, words);
-    if (hipStreamSynchronize(stream) != hipSuccess) {
+                           plan->idxStride, plan->maxNnz, plan->rows, plan->baseIndex, records, words, counts);
+    unsigned long long said[2] = {0, 0};
+    if (hipMemcpyAsync(said, counts, sizeof(said), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(packed);
+        return false;
+    }
+    /* scattered columns: the copy would save nothing (an escape costs its rP word on top of the 16-bit one) -- the matrix keeps its
+     * plan, unfrozen */
+    if (said[1] * 100ull > said[0] * (unsigned long long)(spgpuTuning()->freezeEscapesPct < 0 ? 0 : spgpuTuning()->freezeEscapesPct)) {
         (void)hipFree(packed);
         return false;
     }

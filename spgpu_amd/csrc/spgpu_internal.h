@@ -252,6 +252,8 @@ typedef struct SpgpuTuning {
     int plan;        /* 1: ordered matrices get a per-matrix plan (planned_spmv.hip); 0: never */
     int planDeepSpread; /* 60: the deep sub-groups' workgroups are spread over the first 60 % of the grid; 0: all in front; < 0: all behind */
     int planDeepPerBlock; /* 8: deep sub-groups per such workgroup (1 .. 8) */
+    int freezeEscapesPct; /* 1: spgpu?SpmvFreeze keeps a 16-bit copy only if at most this many entries in a hundred are escapes (0xFFFF: the column is
+                           * in rP after all) -- a matrix with scattered columns gains nothing from the copy and pays for every escape */
     int planDeepRuns;     /* 1: such a workgroup takes a run of consecutive sub-groups of the list; 0: every deepBlocks-th */
     int stageLate;   /* 1: the queue kernel stages its destinations under the tile's round trip (0: before the first requests, as round 3) */
 } SpgpuTuning;

@@ -59,9 +59,10 @@ def _freeze(gpu, letter, h, n, hack=32, base=0):
     (0, 0, False, 32, "near", 500),         # one global sort: a block's rows come from everywhere -- escapes (0xFFFF -> rP) beside offsets
     (2048, 60, True, 32, "random", 0),      # scattered over all of x: mostly escapes
 ])
-def test_frozen_call_equals_unfrozen_call_and_oracle(gpu, letter, window, long_rows, aligned, hack, pattern, near):
+def test_frozen_call_equals_unfrozen_call_and_oracle(gpu, letter, window, long_rows, aligned, hack, pattern, near, tuning):
     import torch
     from spgpu_amd import capi, formats, synth
+    tuning(SPGPU_FREEZE_MAX_ESCAPES_PCT=100)    # the escape paths are what some of these cases are for: freeze whatever the share of escapes
     n = 80 * 1024 + 77 if pattern == "random" or window == 0 else 9 * 2048 + 77
     h = _matrix(gpu, n, letter, window, long_rows, aligned, hack=hack, longest=900, pattern=pattern, near=near)
     sub, r_idx = _host(h, letter, n, hack), h["rIdx"].cpu().numpy()
@@ -119,11 +120,12 @@ def test_coefficients_may_change_under_a_frozen_matrix(gpu):
     assert capi.spgpuSpmvThaw(gpu, _dp(h["rP"])) == capi.SPGPU_SUCCESS
 
 
-def test_negative_columns_and_base_index_one(gpu):
+def test_negative_columns_and_base_index_one(gpu, tuning):
     """Slots whose stored column is below baseIndex are skipped by every kernel of the family (col >= 0); frozen they are escapes.
     baseIndex 1 with the packed words counted from the 0-based column."""
     import torch
     from spgpu_amd import capi, formats, synth
+    tuning(SPGPU_FREEZE_MAX_ESCAPES_PCT=100)            # (one slot in 97 is a hole here: just over the default share)
     n, letter = 5 * 2048 + 64, "D"
     h = _matrix(gpu, n, letter, 2048, 60, True, longest=500)
     h["rP"].add_(1)                                     # 1-based
@@ -167,11 +169,32 @@ def test_calls_without_a_packed_form_say_so(gpu):
     assert dz.cpu().numpy().tobytes() == want.tobytes()
 
 
-def test_frozen_ell(gpu):
+def test_ordered_matrix_with_scattered_columns_keeps_its_plan_but_gets_no_copy(gpu):
+    """More than one escape in a hundred entries (columns all over x): Freeze says SPGPU_UNSUPPORTED, holds no memory, and the calls
+    run from the plan as before."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n, letter = 300 * 1024, "D"                         # (columns must reach beyond 16 bits of a block's lowest to be escapes)
+    h = _matrix(gpu, n, letter, 2048, 60, True, longest=300, pattern="random")
+    assert _freeze(gpu, letter, h, n) == capi.SPGPU_UNSUPPORTED
+    assert capi.spgpuSpmvFrozenBytes(gpu) == 0
+    x = synth.values_for(letter, 3, n)
+    dx = formats.to_device(x)
+    want = O.spmv_tail(_host(h, letter, n), x, None, 1.0, 0.0, r_idx=h["rIdx"].cpu().numpy(), **O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP))
+    dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+    uses0 = capi.plan_counts(gpu)[0]
+    _call(gpu, letter, h, n, dz, None, dx, 1.0, 0.0)
+    torch.cuda.synchronize()
+    assert capi.plan_counts(gpu)[0] == uses0 + 1        # planned (Freeze prepared it), unfrozen
+    assert dz.cpu().numpy().tobytes() == want.tobytes()
+
+
+def test_frozen_ell(gpu, tuning):
     """spgpuEllSpmvFreeze: ELL with a row order (the arrays ellToOell leaves, reference ell.c:161-202) through the same kernels;
     a random order scatters a block's rows over the matrix -- offsets beside the tile and escapes."""
     import torch
     from spgpu_amd import capi, formats, synth
+    tuning(SPGPU_FREEZE_MAX_ESCAPES_PCT=100)
     n = 6000
     lengths = np.minimum(np.random.default_rng(5).zipf(1.5, size=n), 300)
     _, _, r, c, v = synth.random_rows_coo(n, n, lengths, seed=6, letter="D")
