@@ -551,7 +551,7 @@ def bench_c3(handle, stream, dev, rows, ell_rows):
     lengths = synth.power_law_lengths(n, mean=32.0, max_len=2048, seed=5)
     out = {}
 
-    def hell_case(count):
+    def hell_case(count, adopt=False):
         h = synth.hell_ragged_on_device(lengths[:count], count, "S", 32, seed=5, device=dev)
         h["letter"] = "S"
         x, z = synth.device_vector(count, "S", 3, dev), torch.zeros(count, dtype=torch.float32, device=dev)
@@ -562,12 +562,31 @@ def bench_c3(handle, stream, dev, rows, ell_rows):
         t = time_launches(stream, call, 20) / 20
         torch.cuda.synchronize()
         alg = h["nnz"] * 8 + count * 8 + count * 4 + (count // 32) * 4
-        return dict(rows=count, nnz=h["nnz"], ms=round(t * 1e3, 4), gflops=round(2.0 * h["nnz"] / t * 1e-9, 1),
-                    hbm_gbs=round(alg / t * 1e-9, 1), frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4),
-                    footprint_GB=round((h["slots"] * 8 + count * 4 + count // 32 * 4) * 1e-9, 2),
-                    slots_per_nnz=round(h["slots"] / h["nnz"], 3), parity=check_windows(h, x, z, "S", O.slab_shape("S")))
+        entry = dict(rows=count, nnz=h["nnz"], ms=round(t * 1e3, 4), gflops=round(2.0 * h["nnz"] / t * 1e-9, 1),
+                     hbm_gbs=round(alg / t * 1e-9, 1), frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4),
+                     footprint_GB=round((h["slots"] * 8 + count * 4 + count // 32 * 4) * 1e-9, 2),
+                     slots_per_nnz=round(h["slots"] / h["nnz"], 3), parity=check_windows(h, x, z, "S", O.slab_shape("S")))
+        if adopt:
+            # the same call after spgpuHellSpmvAdopt (include/spgpu/tuning.h): the library's ordered copy of the caller's matrix
+            z_plain = z.clone()
+            t0 = time.perf_counter()
+            said = capi.spgpuHellSpmvAdopt(handle, capi.TYPE_CODE["S"], p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]), count, 0)
+            torch.cuda.synchronize()
+            adopt_ms = (time.perf_counter() - t0) * 1e3
+            if said == capi.SPGPU_SUCCESS:
+                time_launches(stream, call, 3)
+                ta = time_launches(stream, call, 20) / 20
+                torch.cuda.synchronize()
+                worst = float(((z - z_plain).abs().max() / z_plain.abs().max()).item())
+                entry["adopted"] = dict(ms=round(ta * 1e3, 4), gflops=round(2.0 * h["nnz"] / ta * 1e-9, 1), frac=round(alg / ta * 1e-9 / HBM_PEAK_GBS, 4),
+                                        adopt_ms=round(adopt_ms, 1), copy_GB=round(capi.spgpuSpmvFrozenBytes(handle) * 1e-9, 2),
+                                        parity=f"max |z - z_plain| / max |z_plain| = {worst:.2e} (another order of additions; bar 1e-4)")
+                capi.spgpuSpmvThaw(handle, p(h["rP"]))
+            else:
+                entry["adopted"] = dict(status=said)
+        return entry
 
-    out["hell_fp32"] = hell_case(n)
+    out["hell_fp32"] = hell_case(n, adopt=True)
     torch.cuda.empty_cache()
     ne = min(ell_rows, n) // 32 * 32
     out["hell_fp32_same_rows_as_ell"] = hell_case(ne)
