@@ -138,8 +138,9 @@ long long spgpuSpmvFrozenBytes(spgpuHandle_t handle);
  * spgpu?hellspmv calls on the caller's arrays with rIdx == NULL run on that copy and write z through its row order: z[i] for
  * the caller's row i, as ever, the value the ordered kernel computes (equal to the plain kernel's within rounding; bit for bit
  * what the caller would get by ordering the matrix himself with the same device calls).  Cost: device memory for the ordered
- * matrix (spgpuSpmvFrozenBytes counts it) and ~17 ms once for the 10 M-row target.  SPGPU_UNSUPPORTED: hackSize not a multiple of 32, no memory, or
- * four matrices adopted already.  Launches captured into a HIP graph run on the caller's arrays.
+ * matrix (spgpuSpmvFrozenBytes counts it) and ~17 ms once for the 10 M-row target.  SPGPU_UNSUPPORTED: hackSize not a multiple of 32, no memory, four
+ * matrices adopted already -- or a matrix that stores less than 1.25 x the slots its ordered copy would (rows about equally long:
+ * nothing to gain; spgpuHellSpmvFreeze is the call for such a matrix).  Launches captured into a HIP graph run on the caller's arrays.
  * spgpuSpmvAdoptedUses: calls that ran on a copy.
  */
 int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,

@@ -152,6 +152,19 @@ extern "C" int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const 
         ok = hipMemcpyAsync(&slots, total, sizeof(slots), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
     }
     ok = ok && slots > 0 && slots < 0x7FFFFFFFull; /* hackOffsets is an int array */
+    if (ok) {
+        /* what the caller's layout stores: its last hack's offset + hackSize x that hack's depth.  A matrix whose rows are about equally
+         * long gains nothing from another order (and would pay the ordered kernel's row indirection): not adopted -- Freeze is the
+         * call for it. */
+        int lastOffset = 0, lastDepth = 0;
+        hipLaunchKernelGGL(adoptHackDepthsKernel, dim3((unsigned)((hacks + kAdoptThreads / kWave - 1) / (kAdoptThreads / kWave))), dim3(kAdoptThreads), 0, stream,
+                           static_cast<int*>(depths), rS, rows, hackSize);
+        ok = hipMemcpyAsync(&lastDepth, static_cast<int*>(depths) + (hacks - 1), sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+             hipMemcpyAsync(&lastOffset, hackOffsets + (hacks - 1), sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+             hipStreamSynchronize(stream) == hipSuccess;
+        const unsigned long long callerSlots = (unsigned long long)(unsigned)lastOffset + (unsigned long long)hackSize * (unsigned)lastDepth;
+        ok = ok && callerSlots * 4ull >= slots * 5ull; /* at least 1.25 x the ordered matrix' slots */
+    }
     if (ok)
         ok = hipMalloc(&e.values, (size_t)slots * elem) == hipSuccess && hipMalloc((void**)&e.indices, (size_t)slots * sizeof(int)) == hipSuccess;
     if (ok) {

@@ -136,3 +136,13 @@ def test_fifth_matrix_is_not_adopted_and_odd_hack_sizes_are_refused(gpu):
     coo = _coo(n, letter, "near", 300, 400, 8.0, 40)
     odd = formats.coo_to_ordered_hell_device(gpu, n, *coo, letter, 48, 0, 0, order=False)
     assert capi.spgpuHellSpmvAdopt(gpu, code, _dp(odd["cM"]), _dp(odd["rP"]), 48, _dp(odd["hack_offsets"]), _dp(odd["rS"]), n, 0) == capi.SPGPU_UNSUPPORTED
+
+
+def test_a_matrix_with_rows_of_equal_length_is_not_adopted(gpu):
+    """Nothing to gain from another order: SPGPU_UNSUPPORTED, no memory held (Freeze is the call for such a matrix)."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 20 * 1024
+    h = synth.hell_uniform_on_device(n, 16, "banded", "D", 32, seed=1)
+    assert capi.spgpuHellSpmvAdopt(gpu, capi.TYPE_CODE["D"], _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), n, 0) == capi.SPGPU_UNSUPPORTED
+    assert capi.spgpuSpmvFrozenBytes(gpu) == 0
