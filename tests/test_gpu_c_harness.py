@@ -105,3 +105,24 @@ def test_cg_converges():
     assert "PASSED" in out and out.count("bit-identical to the eager run") == 2     # the 8-kernel graph and the fused one
     last = [l for l in out.splitlines() if "relative residual" in l][-1]
     assert float(last.split("max |x - 1| =")[1]) < 1e-6
+
+
+def test_hellperf_adopts_a_ragged_matrix_market_file(tmp_path):
+    """A matrix with very unequal row lengths from a .mtx file: the harness' fourth leg (spgpuHellSpmvAdopt from plain C, then the
+    same spgpuDhellspmv loop without rIdx) runs on the library's ordered copy and prints the checksum of the plain run within
+    rounding; the reference's own remedy -- ellToOell + rIdx, the OELL leg -- beside it."""
+    import numpy as np
+    n = 6000
+    rng = np.random.default_rng(11)
+    lengths = np.minimum(rng.zipf(1.5, size=n) + 1, 500)
+    path = tmp_path / "ragged.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{n} {n} {int(lengths.sum())}\n")
+        for i in range(n):
+            cols = np.sort(rng.choice(n, int(lengths[i]), replace=False))
+            for j in cols:
+                f.write(f"{i + 1} {j + 1} {rng.standard_normal():.17g}\n")
+    out = _run("hellperf_amd", path, 5, "d")
+    assert "checksums identical: PASSED" in out and "OELL checksum equal within rounding: PASSED" in out
+    assert "HELL adopted dot res" in out and "adopted HELL checksum equal within rounding: PASSED" in out
