@@ -141,7 +141,7 @@ long long spgpuSpmvFrozenBytes(spgpuHandle_t handle);
  * matrix (spgpuSpmvFrozenBytes counts it) and ~17 ms once for the 10 M-row target.  SPGPU_UNSUPPORTED: hackSize not a multiple of 32, no memory, four
  * matrices adopted already -- or a matrix that stores less than 1.25 x the slots its ordered copy would (rows about equally long:
  * nothing to gain; spgpuHellSpmvFreeze is the call for such a matrix).  Launches captured into a HIP graph run on the caller's arrays.
- * spgpuSpmvAdoptedUses: calls that ran on a copy.
+ * spgpuSpmvAdoptedUses: calls that ran on a copy.  (Adopt, Freeze and Thaw synchronise the handle's stream: not inside a capture.)
  */
 int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,
                        int rows, int baseIndex);
