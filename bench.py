@@ -602,6 +602,27 @@ def bench_c3(handle, stream, dev, rows, ell_rows):
     out["ell_fp32"] = dict(rows=ne, nnz=e["nnz"], ms=round(t * 1e3, 4), gflops=round(2.0 * e["nnz"] / t * 1e-9, 1),
                            hbm_gbs=round(alg / t * 1e-9, 1), frac=round(alg / t * 1e-9 / HBM_PEAK_GBS, 4),
                            footprint_GB=round((e["pitch"] * e["max_row"] * 8 + ne * 4) * 1e-9, 2))
+    # the same spgpuSellspmv call after spgpuEllSpmvAdopt: the library's ordered HELL copy of the caller's ELL matrix
+    try:
+        z_plain = z.clone()
+        t0 = time.perf_counter()
+        said = capi.spgpuEllSpmvAdopt(handle, capi.TYPE_CODE["S"], p(e["cM"]), p(e["rP"]), e["pitch"], e["pitch"], p(e["rS"]), e["max_row"], ne, 0)
+        torch.cuda.synchronize()
+        adopt_ms = (time.perf_counter() - t0) * 1e3
+        if said == capi.SPGPU_SUCCESS:
+            time_launches(stream, call, 3)
+            ta = time_launches(stream, call, 20) / 20
+            torch.cuda.synchronize()
+            worst = float(((z - z_plain).abs().max() / z_plain.abs().max()).item())
+            out["ell_fp32"]["adopted"] = dict(ms=round(ta * 1e3, 4), gflops=round(2.0 * e["nnz"] / ta * 1e-9, 1), adopt_ms=round(adopt_ms, 1),
+                                              copy_GB=round(capi.spgpuSpmvFrozenBytes(handle) * 1e-9, 2),
+                                              parity=f"max |z - z_plain| / max |z_plain| = {worst:.2e} (another order of additions; bar 1e-4)")
+            capi.spgpuSpmvThaw(handle, p(e["rP"]))
+        else:
+            out["ell_fp32"]["adopted"] = dict(status=said)
+        del z_plain
+    except Exception as error:  # noqa: BLE001
+        out["ell_fp32"]["adopted"] = dict(error=repr(error))
     out["ell_footprint_GB_at_full_rows"] = round(((n + 31) // 32 * 32) * int(lengths.max()) * 8e-9 + n * 4e-9, 1)
     del e, x, z
     torch.cuda.empty_cache()

@@ -145,6 +145,10 @@ long long spgpuSpmvFrozenBytes(spgpuHandle_t handle);
  */
 int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,
                        int rows, int baseIndex);
+/* The ELL flavour (same promise, same Thaw): spgpu?ellspmv calls with rIdx == NULL and these arrays run on an ordered HELL copy (hack
+ * size 32) -- rows x maxNnzPerRow slots in the caller's layout, ~1.1 per nonzero in the copy.  Needs rS. */
+int spgpuEllSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int cMPitch, int rPPitch, const int* rS,
+                      int maxNnzPerRow, int rows, int baseIndex);
 int spgpuSpmvAdoptedUses(spgpuHandle_t handle);
 
 void spgpuTuningReload(void);

@@ -263,6 +263,7 @@ spgpuHellSpmvPrepare = _decl("spgpuHellSpmvPrepare", i32, [Handle, i32, ptr, ptr
 spgpuHellSpmvFreeze = _decl("spgpuHellSpmvFreeze", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, ptr, i32, i32])
 spgpuEllSpmvFreeze = _decl("spgpuEllSpmvFreeze", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, ptr, i32, i32, i32])
 spgpuHellSpmvAdopt = _decl("spgpuHellSpmvAdopt", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, i32, i32])
+spgpuEllSpmvAdopt = _decl("spgpuEllSpmvAdopt", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, i32, i32, i32])
 spgpuSpmvAdoptedUses = _decl("spgpuSpmvAdoptedUses", i32, [Handle])
 spgpuSpmvThaw = _decl("spgpuSpmvThaw", i32, [Handle, ptr])
 spgpuSpmvFrozenBytes = _decl("spgpuSpmvFrozenBytes", C.c_longlong, [Handle])

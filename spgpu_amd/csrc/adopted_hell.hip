@@ -85,48 +85,61 @@ __global__ __launch_bounds__(1024) void adoptHackOffsetsKernel(int* __restrict__
 }
 
 /* the entries of row order[i] of the caller's matrix become row i of the copy, slab column for slab column */
+/* (source HELL: hackOffsets != NULL, slot of (row r, k) = hackOffsets[r / hs] + r % hs + k * hs; source ELL: r + k * pitch, with one pitch
+ * for the coefficients and one for the indices (ell.h:46-61)) */
 template <typename Raw>
 __global__ __launch_bounds__(kAdoptThreads) void adoptCopyKernel(Raw* __restrict__ values, int* __restrict__ indices, const int* __restrict__ hackOffsetsOrdered,
-                                                               const int* __restrict__ order, const int* __restrict__ lengths, const Raw* __restrict__ cM,
-                                                               const int* __restrict__ rP, const int* __restrict__ hackOffsets, int hackSize, int rows)
+                                                               int copyHackSize, const int* __restrict__ order, const int* __restrict__ lengths,
+                                                               const Raw* __restrict__ cM, const int* __restrict__ rP, const int* __restrict__ hackOffsets,
+                                                               int hackSize, long long valPitch, long long idxPitch, int rows)
 {
     const long long i = (long long)blockIdx.x * kAdoptThreads + threadIdx.x;
     if (i >= rows)
         return;
-    const unsigned hs = (unsigned)hackSize;
-    const unsigned from = (unsigned)order[i], to = (unsigned)i;
-    long long src = (long long)((unsigned)hackOffsets[from / hs] + from % hs);
-    long long dst = (long long)((unsigned)hackOffsetsOrdered[to / hs] + to % hs);
+    const unsigned from = (unsigned)order[i], to = (unsigned)i, chs = (unsigned)copyHackSize;
+    long long srcV, srcI, stepV, stepI;
+    if (hackOffsets) {
+        const unsigned hs = (unsigned)hackSize;
+        srcV = srcI = (long long)((unsigned)hackOffsets[from / hs] + from % hs);
+        stepV = stepI = hs;
+    } else {
+        srcV = srcI = from;
+        stepV = valPitch;
+        stepI = idxPitch;
+    }
+    long long dst = (long long)((unsigned)hackOffsetsOrdered[to / chs] + to % chs);
     const int len = lengths[i];
-    for (int k = 0; k < len; ++k, src += hs, dst += hs) {
-        values[dst] = cM[src];
-        indices[dst] = rP[src];
+    for (int k = 0; k < len; ++k, srcV += stepV, srcI += stepI, dst += chs) {
+        values[dst] = cM[srcV];
+        indices[dst] = rP[srcI];
     }
 }
 
 template <typename Raw>
-static void launchCopy(hipStream_t s, void* values, int* indices, const int* hackOffsetsOrdered, const int* order, const int* lengths, const void* cM,
-                       const int* rP, const int* hackOffsets, int hackSize, int rows)
+static void launchCopy(hipStream_t s, void* values, int* indices, const int* hackOffsetsOrdered, int copyHackSize, const int* order, const int* lengths,
+                       const void* cM, const int* rP, const int* hackOffsets, int hackSize, long long valPitch, long long idxPitch, int rows)
 {
     hipLaunchKernelGGL((adoptCopyKernel<Raw>), dim3((unsigned)(((long long)rows + kAdoptThreads - 1) / kAdoptThreads)), dim3(kAdoptThreads), 0, s,
-                       static_cast<Raw*>(values), indices, hackOffsetsOrdered, order, lengths, static_cast<const Raw*>(cM), rP, hackOffsets, hackSize, rows);
+                       static_cast<Raw*>(values), indices, hackOffsetsOrdered, copyHackSize, order, lengths, static_cast<const Raw*>(cM), rP, hackOffsets,
+                       hackSize, valPitch, idxPitch, rows);
 }
 
 } // namespace spgpu
 
-extern "C" int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets,
-                                  const int* rS, int rows, int baseIndex)
+/* The caller's matrix: HELL (hackOffsets != NULL; pitches 0) or ELL (hackOffsets NULL, callerHackSize 0, the two pitches and maxNnz).
+ * The copy is HELL with copyHackSize rows per hack (the caller's hack size; 32 for an ELL source). */
+static int adoptMatrix(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int callerHackSize, const int* hackOffsets, const int* rS,
+                       int rows, int baseIndex, long long valPitch, long long idxPitch, int maxNnz)
 {
     using namespace spgpu;
-    if (!handle || !cM || !rP || !hackOffsets || !rS || rows <= 0 || hackSize <= 0)
-        return SPGPU_UNSPECIFIED;
     const size_t elem = spgpuSizeOf(type);
     if (elem != 4 && elem != 8 && elem != 16)
         return SPGPU_UNSPECIFIED;
+    const int hackSize = hackOffsets ? callerHackSize : 32;
     if (hackSize % 32 != 0)
         return SPGPU_UNSUPPORTED; /* (the ordered kernels' 32-row sub-groups are whole parts of a hack) */
     hipStream_t stream = handle->currentStream;
-    if (spgpuAdoptedFind(handle, stream, cM, rP, rS, hackOffsets, rows, hackSize, baseIndex))
+    if (spgpuAdoptedFind(handle, stream, cM, rP, rS, hackOffsets, rows, callerHackSize, baseIndex, valPitch, idxPitch))
         return SPGPU_SUCCESS; /* already adopted */
     const long long hacks = ((long long)rows + hackSize - 1) / hackSize;
     int previous = 0;
@@ -156,13 +169,18 @@ extern "C" int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const 
         /* what the caller's layout stores: its last hack's offset + hackSize x that hack's depth.  A matrix whose rows are about equally
          * long gains nothing from another order (and would pay the ordered kernel's row indirection): not adopted -- Freeze is the
          * call for it. */
-        int lastOffset = 0, lastDepth = 0;
-        hipLaunchKernelGGL(adoptHackDepthsKernel, dim3((unsigned)((hacks + kAdoptThreads / kWave - 1) / (kAdoptThreads / kWave))), dim3(kAdoptThreads), 0, stream,
-                           static_cast<int*>(depths), rS, rows, hackSize);
-        ok = hipMemcpyAsync(&lastDepth, static_cast<int*>(depths) + (hacks - 1), sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-             hipMemcpyAsync(&lastOffset, hackOffsets + (hacks - 1), sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-             hipStreamSynchronize(stream) == hipSuccess;
-        const unsigned long long callerSlots = (unsigned long long)(unsigned)lastOffset + (unsigned long long)hackSize * (unsigned)lastDepth;
+        unsigned long long callerSlots = 0;
+        if (hackOffsets) {
+            int lastOffset = 0, lastDepth = 0;
+            hipLaunchKernelGGL(adoptHackDepthsKernel, dim3((unsigned)((hacks + kAdoptThreads / kWave - 1) / (kAdoptThreads / kWave))), dim3(kAdoptThreads), 0,
+                               stream, static_cast<int*>(depths), rS, rows, hackSize);
+            ok = hipMemcpyAsync(&lastDepth, static_cast<int*>(depths) + (hacks - 1), sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                 hipMemcpyAsync(&lastOffset, hackOffsets + (hacks - 1), sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+                 hipStreamSynchronize(stream) == hipSuccess;
+            callerSlots = (unsigned long long)(unsigned)lastOffset + (unsigned long long)hackSize * (unsigned)lastDepth;
+        } else {
+            callerSlots = (unsigned long long)rows * (unsigned long long)(maxNnz > 0 ? maxNnz : 0); /* ELL: every row as long as the longest */
+        }
         ok = ok && callerSlots * 4ull >= slots * 5ull; /* at least 1.25 x the ordered matrix' slots */
     }
     if (ok)
@@ -173,11 +191,11 @@ extern "C" int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const 
             (void)hipMemsetAsync(e.indices, 0xFF, (size_t)slots * sizeof(int), stream);
         }
         if (elem == 4)
-            launchCopy<uint32_t>(stream, e.values, e.indices, e.hackOffsetsOrdered, e.order, e.lengths, cM, rP, hackOffsets, hackSize, rows);
+            launchCopy<uint32_t>(stream, e.values, e.indices, e.hackOffsetsOrdered, hackSize, e.order, e.lengths, cM, rP, hackOffsets, callerHackSize, valPitch, idxPitch, rows);
         else if (elem == 8)
-            launchCopy<unsigned long long>(stream, e.values, e.indices, e.hackOffsetsOrdered, e.order, e.lengths, cM, rP, hackOffsets, hackSize, rows);
+            launchCopy<unsigned long long>(stream, e.values, e.indices, e.hackOffsetsOrdered, hackSize, e.order, e.lengths, cM, rP, hackOffsets, callerHackSize, valPitch, idxPitch, rows);
         else
-            launchCopy<RawBits<16>::type>(stream, e.values, e.indices, e.hackOffsetsOrdered, e.order, e.lengths, cM, rP, hackOffsets, hackSize, rows);
+            launchCopy<RawBits<16>::type>(stream, e.values, e.indices, e.hackOffsetsOrdered, hackSize, e.order, e.lengths, cM, rP, hackOffsets, callerHackSize, valPitch, idxPitch, rows);
         ok = hipStreamSynchronize(stream) == hipSuccess;
     }
     if (work)
@@ -191,7 +209,9 @@ extern "C" int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const 
         e.rS = rS;
         e.hackOffsets = hackOffsets;
         e.rows = rows;
-        e.hackSize = hackSize;
+        e.hackSize = callerHackSize;
+        e.valPitch = valPitch;
+        e.idxPitch = idxPitch;
         e.baseIndex = baseIndex;
         e.type = (int)type;
         e.bytes = (long long)((size_t)slots * (elem + sizeof(int)) + (size_t)rows * 2 * sizeof(int) + (size_t)hacks * sizeof(int));
@@ -212,4 +232,25 @@ extern "C" int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const 
         return SPGPU_UNSUPPORTED;
     }
     return SPGPU_SUCCESS;
+}
+
+extern "C" int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets,
+                                  const int* rS, int rows, int baseIndex)
+{
+    if (!handle || !cM || !rP || !hackOffsets || !rS || rows <= 0 || hackSize <= 0)
+        return SPGPU_UNSPECIFIED;
+    return adoptMatrix(handle, type, cM, rP, hackSize, hackOffsets, rS, rows, baseIndex, 0, 0, 0);
+}
+
+/* The ELL flavour: the ordered copy is HELL (hack size 32) -- the memory argument of BASELINE configs[2] inside the library: a ragged ELL
+ * matrix stores rows x maxNnzPerRow slots, its ordered HELL copy ~1.1 per nonzero.  rS is needed (without row lengths ELL has no
+ * ragged rows to order: SPGPU_UNSUPPORTED). */
+extern "C" int spgpuEllSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int cMPitch, int rPPitch, const int* rS,
+                                 int maxNnzPerRow, int rows, int baseIndex)
+{
+    if (!handle || !cM || !rP || rows <= 0 || cMPitch < rows || rPPitch < rows || maxNnzPerRow < 0)
+        return SPGPU_UNSPECIFIED;
+    if (!rS)
+        return SPGPU_UNSUPPORTED;
+    return adoptMatrix(handle, type, cM, rP, 0, nullptr, rS, rows, baseIndex, cMPitch, rPPitch, maxNnzPerRow);
 }

@@ -462,7 +462,7 @@ void spgpuSpmvPlanCounts(spgpuHandle_t pHandle, int* uses, int* builds, int* sta
 
 /* ---- adopted matrices (spgpu_internal.h, csrc/adopted_hell.hip) ---- */
 const SpgpuAdopted* spgpuAdoptedFind(spgpuHandle_t pHandle, hipStream_t stream, const void* cM, const int* rP, const int* rS,
-                                     const int* hackOffsets, int rows, int hackSize, int baseIndex)
+                                     const int* hackOffsets, int rows, int hackSize, int baseIndex, long long valPitch, long long idxPitch)
 {
     SpgpuPrivateHandle* h = spgpuPrivate(pHandle);
     if (!h->adopted || __atomic_load_n(&h->adoptedCount, __ATOMIC_RELAXED) <= 0)
@@ -477,7 +477,7 @@ const SpgpuAdopted* spgpuAdoptedFind(spgpuHandle_t pHandle, hipStream_t stream, 
     for (int i = 0; i < SPGPU_ADOPTED; ++i) {
         const SpgpuAdopted* e = &h->adopted[i];
         if (e->rows > 0 && e->rP == (const void*)rP && e->cM == cM && e->rS == (const void*)rS && e->hackOffsets == (const void*)hackOffsets &&
-            e->rows == rows && e->hackSize == hackSize && e->baseIndex == baseIndex) {
+            e->rows == rows && e->hackSize == hackSize && e->baseIndex == baseIndex && e->valPitch == valPitch && e->idxPitch == idxPitch) {
             found = e;
             h->adoptedUses += 1;
             break;

@@ -1835,7 +1835,7 @@ static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     /* an ADOPTED matrix (spgpuHellSpmvAdopt, adopted_hell.hip): the call runs on the library's ordered copy and writes z through the
      * copy's row order -- z in the caller's row order, as ever */
     if (!rIdx) {
-        if (const SpgpuAdopted* copy = spgpuAdoptedFind(handle, handle->currentStream, cM, rP, rS, hackOffsets, rows, hackSize, baseIndex)) {
+        if (const SpgpuAdopted* copy = spgpuAdoptedFind(handle, handle->currentStream, cM, rP, rS, hackOffsets, rows, hackSize, baseIndex, 0, 0)) {
             cM = static_cast<const ApiT*>(copy->values);
             rP = copy->indices;
             hackOffsets = copy->hackOffsetsOrdered;
@@ -1879,6 +1879,14 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
                     const ApiT* x, ApiT beta, int baseIndex, int avgNnzPerRow = 0)
 {
     static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
+    /* an ADOPTED ELL matrix (spgpuEllSpmvAdopt, adopted_hell.hip): the call runs on the library's ordered HELL copy */
+    if (!rIdx && rS) {
+        if (const SpgpuAdopted* copy = spgpuAdoptedFind(handle, handle->currentStream, cM, rP, rS, nullptr, rows, 0, baseIndex, cMPitch, rPPitch)) {
+            hellSpmv<T, ApiT>(handle, z, y, alpha, static_cast<const ApiT*>(copy->values), copy->indices, 32, copy->hackOffsetsOrdered, copy->lengths,
+                              copy->order, rows, x, beta, baseIndex, avgNnzPerRow);
+            return;
+        }
+    }
     SlabArgs<T> a;
     a.z = reinterpret_cast<T*>(z);
     a.y = reinterpret_cast<const T*>(y);

@@ -171,8 +171,9 @@ SpgpuSpmvPlan* spgpuPlanFind(spgpuHandle_t h, const SpgpuSpmvPlan* key);
 /* An adopted matrix: the caller's arrays (the key) and the library's ordered copy of them. */
 #define SPGPU_ADOPTED 4
 typedef struct SpgpuAdopted {
-    const void *cM, *rP, *rS, *hackOffsets; /* the caller's (key; rows == 0: free entry) */
+    const void *cM, *rP, *rS, *hackOffsets; /* the caller's (key; rows == 0: free entry); ELL: hackOffsets NULL, hackSize 0 */
     int rows, hackSize, baseIndex, type;
+    long long valPitch, idxPitch;           /* ELL: the caller's pitches (key); HELL: 0 */
     void* values;       /* ordered copy: coefficients */
     int* indices;       /* column indices */
     int* hackOffsetsOrdered;
@@ -182,7 +183,7 @@ typedef struct SpgpuAdopted {
 } SpgpuAdopted;
 /* No lock held.  The ordered copy of these arrays, or NULL (none, or the stream is capturing: a graph would outlive the copy). */
 const SpgpuAdopted* spgpuAdoptedFind(spgpuHandle_t h, hipStream_t stream, const void* cM, const int* rP, const int* rS, const int* hackOffsets,
-                                     int rows, int hackSize, int baseIndex);
+                                     int rows, int hackSize, int baseIndex, long long valPitch, long long idxPitch);
 /* No lock held.  Takes a free entry for `entry` (copied); SPGPU_UNSUPPORTED when the table is full. */
 int spgpuAdoptedAdd(spgpuHandle_t h, const SpgpuAdopted* entry);
 /* No lock held.  Removes the entries keyed by rP (NULL: all); their arrays are returned in `out` (at most SPGPU_ADOPTED) for the caller to free. */

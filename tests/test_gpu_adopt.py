@@ -146,3 +146,39 @@ def test_a_matrix_with_rows_of_equal_length_is_not_adopted(gpu):
     h = synth.hell_uniform_on_device(n, 16, "banded", "D", 32, seed=1)
     assert capi.spgpuHellSpmvAdopt(gpu, capi.TYPE_CODE["D"], _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), n, 0) == capi.SPGPU_UNSUPPORTED
     assert capi.spgpuSpmvFrozenBytes(gpu) == 0
+
+
+@pytest.mark.parametrize("letter", ["D", "S"])
+def test_adopted_ell_runs_on_an_ordered_hell_copy(gpu, letter):
+    """spgpuEllSpmvAdopt: a ragged ELL matrix (rows x maxNnzPerRow slots) of which the library keeps an ordered HELL copy; the
+    spgpu?ellspmv call without rIdx then gives the bits of the explicitly ordered HELL call (the same COO through
+    spgpuOellOrderAlignedDevice + spgpuCooToHellDevice) and of the oracle; Thaw gives the plain ELL kernel's bits back."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    n = 5 * 2048 + 100
+    coo = _coo(n, letter, "near", 400, 600, 10.0, 9)
+    rows_h, cols_h, vals_h = (t.cpu().numpy() for t in coo)
+    ell = formats.coo_to_ell(n, rows_h, cols_h, vals_h)
+    dev = formats.DeviceEll(ell)
+    ordered = formats.coo_to_ordered_hell_device(gpu, n, *coo, letter, 32, 2048, 256, aligned=True)
+    x, y = synth.values_for(letter, 3, n), synth.values_for(letter, 4, n)
+    dx, dy = formats.to_device(x), formats.to_device(y)
+    want_plain = O.default_spmv(ell, x, y, 1.5, -1.0)
+    want = O.spmv_tail(_host(ordered, letter, n), x, y, 1.5, -1.0, r_idx=ordered["rIdx"].cpu().numpy(), **O.slab_shape(letter, "ragged", deep_cap=O.DEEP_CAP))
+
+    def product():
+        dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+        dev.spmv(gpu, dz, dy, 1.5, dx, -1.0)
+        torch.cuda.synchronize()
+        return dz.cpu().numpy()
+
+    assert product().tobytes() == want_plain.tobytes()
+    assert capi.spgpuEllSpmvAdopt(gpu, capi.TYPE_CODE[letter], _dp(dev.cM), _dp(dev.rP), dev.pitch, dev.pitch, _dp(dev.rS), dev.max_row, n, 0) == capi.SPGPU_SUCCESS
+    assert 0 < capi.spgpuSpmvFrozenBytes(gpu) < dev.pitch * dev.max_row * (dev.cM.element_size() + 4)     # the copy is smaller than the caller's ELL
+    uses0 = capi.spgpuSpmvAdoptedUses(gpu)
+    assert product().tobytes() == want.tobytes()
+    assert capi.spgpuSpmvAdoptedUses(gpu) == uses0 + 1
+    assert capi.spgpuEllSpmvAdopt(gpu, capi.TYPE_CODE[letter], _dp(dev.cM), _dp(dev.rP), dev.pitch, dev.pitch, None, dev.max_row, n, 0) == capi.SPGPU_UNSUPPORTED
+    assert capi.spgpuSpmvThaw(gpu, _dp(dev.rP)) == capi.SPGPU_SUCCESS
+    assert capi.spgpuSpmvFrozenBytes(gpu) == 0
+    assert product().tobytes() == want_plain.tobytes()
