@@ -1835,7 +1835,8 @@ static void hellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, c
     /* an ADOPTED matrix (spgpuHellSpmvAdopt, adopted_hell.hip): the call runs on the library's ordered copy and writes z through the
      * copy's row order -- z in the caller's row order, as ever */
     if (!rIdx) {
-        if (const SpgpuAdopted* copy = spgpuAdoptedFind(handle, handle->currentStream, cM, rP, rS, hackOffsets, rows, hackSize, baseIndex, 0, 0)) {
+        const SpgpuAdopted* copy = spgpuAdoptedFind(handle, handle->currentStream, cM, rP, rS, hackOffsets, rows, hackSize, baseIndex, 0, 0);
+        if (copy && spgpuSizeOf((spgpuType_t)copy->type) == sizeof(T)) { /* (adopted as another type: the call runs on the caller's arrays) */
             cM = static_cast<const ApiT*>(copy->values);
             rP = copy->indices;
             hackOffsets = copy->hackOffsetsOrdered;
@@ -1881,7 +1882,8 @@ static void ellSpmv(spgpuHandle_t handle, ApiT* z, const ApiT* y, ApiT alpha, co
     static_assert(sizeof(T) == sizeof(ApiT), "ABI type and device type must have one layout");
     /* an ADOPTED ELL matrix (spgpuEllSpmvAdopt, adopted_hell.hip): the call runs on the library's ordered HELL copy */
     if (!rIdx && rS) {
-        if (const SpgpuAdopted* copy = spgpuAdoptedFind(handle, handle->currentStream, cM, rP, rS, nullptr, rows, 0, baseIndex, cMPitch, rPPitch)) {
+        const SpgpuAdopted* copy = spgpuAdoptedFind(handle, handle->currentStream, cM, rP, rS, nullptr, rows, 0, baseIndex, cMPitch, rPPitch);
+        if (copy && spgpuSizeOf((spgpuType_t)copy->type) == sizeof(T)) {
             hellSpmv<T, ApiT>(handle, z, y, alpha, static_cast<const ApiT*>(copy->values), copy->indices, 32, copy->hackOffsetsOrdered, copy->lengths,
                               copy->order, rows, x, beta, baseIndex, avgNnzPerRow);
             return;
