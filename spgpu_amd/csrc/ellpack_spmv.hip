@@ -88,7 +88,8 @@ template <typename T, int RPL, int PH, bool IS_HELL, bool NT, int UNROLL, int PI
 __global__ __launch_bounds__(BLOCK) void slabSpmvKernel(const SlabArgs<T> a)
 {
     /* (PACKED, measured: the fp64 kernel needs 140 VGPRs -- 3 wavefronts per SIMD, as the unpacked kernel's 146.  Capped at 128 for a
-     * fourth wavefront -- amdgpu_waves_per_eu(4, 4) -- it spills 52-64 bytes per lane into its stage loop: 0.575 -> 0.896 ms.) */
+     * fourth wavefront -- amdgpu_waves_per_eu(4, 4) -- it spills 52-64 bytes per lane into its stage loop: 0.575 -> 0.896 ms; with
+     * the stage consumed in two halves (16 instead of 32 registers of x alive) 56-152 bytes still.) */
     static_assert(!PACKED || (TILE_BYTES == 0 && !DEEP && RPL >= 2 && XPOLICY == 0), "packed indices: the gather and strip forms of 4- and 8-byte elements");
     using ColumnWord = typename std::conditional<PACKED, unsigned short, int>::type;
     constexpr int LPC = kWave / PH;         /* lanes that cover one slab column */
