@@ -150,6 +150,13 @@ int spgpuHellSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, c
 int spgpuEllSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int cMPitch, int rPPitch, const int* rS,
                       int maxNnzPerRow, int rows, int baseIndex);
 int spgpuSpmvAdoptedUses(spgpuHandle_t handle);
+/* One call for a solver (Adopt's promise: no array of the matrix changes until spgpuSpmvThaw): Adopt if the matrix comes without a row
+ * order and is ragged, else Freeze if its columns allow a 16-bit copy, else nothing.  Returns what the later calls will run on. */
+#define SPGPU_SPMV_AS_IS 0
+#define SPGPU_SPMV_FROZEN 1
+#define SPGPU_SPMV_ADOPTED 2
+int spgpuHellSpmvOptimize(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets, const int* rS,
+                          const int* rIdx, int rows, int baseIndex);
 
 void spgpuTuningReload(void);
 /* 1 if the library was built with -DSPGPU_TUNING_VARIANTS: the non-default kernel shapes (SPGPU_SPMV_VARIANT, SPGPU_X_TILE_SHAPE,

@@ -264,6 +264,8 @@ spgpuHellSpmvFreeze = _decl("spgpuHellSpmvFreeze", i32, [Handle, i32, ptr, ptr, 
 spgpuEllSpmvFreeze = _decl("spgpuEllSpmvFreeze", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, ptr, i32, i32, i32])
 spgpuHellSpmvAdopt = _decl("spgpuHellSpmvAdopt", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, i32, i32])
 spgpuEllSpmvAdopt = _decl("spgpuEllSpmvAdopt", i32, [Handle, i32, ptr, ptr, i32, i32, ptr, i32, i32, i32])
+spgpuHellSpmvOptimize = _decl("spgpuHellSpmvOptimize", i32, [Handle, i32, ptr, ptr, i32, ptr, ptr, ptr, i32, i32])
+SPMV_AS_IS, SPMV_FROZEN, SPMV_ADOPTED = 0, 1, 2
 spgpuSpmvAdoptedUses = _decl("spgpuSpmvAdoptedUses", i32, [Handle])
 spgpuSpmvThaw = _decl("spgpuSpmvThaw", i32, [Handle, ptr])
 spgpuSpmvFrozenBytes = _decl("spgpuSpmvFrozenBytes", C.c_longlong, [Handle])

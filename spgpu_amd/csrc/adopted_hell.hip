@@ -254,3 +254,16 @@ extern "C" int spgpuEllSpmvAdopt(spgpuHandle_t handle, spgpuType_t type, const v
         return SPGPU_UNSUPPORTED;
     return adoptMatrix(handle, type, cM, rP, 0, nullptr, rS, rows, baseIndex, cMPitch, rPPitch, maxNnzPerRow);
 }
+
+/* One call for a solver that will multiply by this matrix many times and touch none of its arrays in between (Adopt's promise, which
+ * includes Freeze's): the ordered copy if the rows are ragged and come without an order, else the 16-bit index copy if the columns
+ * allow one, else nothing -- says which. */
+extern "C" int spgpuHellSpmvOptimize(spgpuHandle_t handle, spgpuType_t type, const void* cM, const int* rP, int hackSize, const int* hackOffsets,
+                                     const int* rS, const int* rIdx, int rows, int baseIndex)
+{
+    if (!rIdx && spgpuHellSpmvAdopt(handle, type, cM, rP, hackSize, hackOffsets, rS, rows, baseIndex) == SPGPU_SUCCESS)
+        return SPGPU_SPMV_ADOPTED;
+    if (spgpuHellSpmvFreeze(handle, type, cM, rP, hackSize, hackOffsets, rS, rIdx, rows, baseIndex) == SPGPU_SUCCESS)
+        return SPGPU_SPMV_FROZEN;
+    return SPGPU_SPMV_AS_IS;
+}

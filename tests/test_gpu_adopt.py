@@ -182,3 +182,32 @@ def test_adopted_ell_runs_on_an_ordered_hell_copy(gpu, letter):
     assert capi.spgpuSpmvThaw(gpu, _dp(dev.rP)) == capi.SPGPU_SUCCESS
     assert capi.spgpuSpmvFrozenBytes(gpu) == 0
     assert product().tobytes() == want_plain.tobytes()
+
+
+def test_optimize_picks_adopt_freeze_or_nothing(gpu):
+    """spgpuHellSpmvOptimize: a ragged matrix without an order is adopted, a band matrix frozen, a matrix with scattered columns and
+    rows of equal length left as it is, an ordered matrix frozen -- and every later call gives the bits the chosen path is pinned to."""
+    import torch
+    from spgpu_amd import capi, formats, synth
+    code = capi.TYPE_CODE["D"]
+    n = 4 * 2048
+    ragged = formats.coo_to_ordered_hell_device(gpu, n, *_coo(n, "D", "near", 400, 600, 10.0, 5), "D", 32, 0, 0, order=False)
+    band = synth.hell_uniform_on_device(n, 16, "banded", "D", 32, seed=1)
+    big = 300 * 1024
+    scattered = synth.hell_uniform_on_device(big, 8, "random", "D", 32, seed=2)
+    ordered = formats.coo_to_ordered_hell_device(gpu, n, *_coo(n, "D", "near", 400, 600, 10.0, 6), "D", 32, 2048, 256, aligned=True)
+    opt = lambda h, rows, r_idx=None: capi.spgpuHellSpmvOptimize(gpu, code, _dp(h["cM"]), _dp(h["rP"]), 32, _dp(h["hack_offsets"]), _dp(h["rS"]), _dp(r_idx), rows, 0)
+    assert opt(ragged, n) == capi.SPMV_ADOPTED
+    assert opt(band, n) == capi.SPMV_FROZEN
+    assert opt(scattered, big) == capi.SPMV_AS_IS
+    assert opt(ordered, n, ordered["rIdx"]) == capi.SPMV_FROZEN
+    x = synth.values_for("D", 8, n)
+    dx = formats.to_device(x)
+    dz = torch.full((n,), float("nan"), dtype=dx.dtype, device="cuda")
+    _call(gpu, "D", ordered, n, dz, None, dx, 1.0, 0.0)
+    torch.cuda.synchronize()
+    want = O.spmv_tail(_host(ordered, "D", n), x, None, 1.0, 0.0, r_idx=ordered["rIdx"].cpu().numpy(), **O.slab_shape("D", "ragged", deep_cap=O.DEEP_CAP))
+    assert dz.cpu().numpy().tobytes() == want.tobytes()
+    for h in (ragged, band, ordered):
+        assert capi.spgpuSpmvThaw(gpu, _dp(h["rP"])) == capi.SPGPU_SUCCESS
+    assert capi.spgpuSpmvFrozenBytes(gpu) == 0
