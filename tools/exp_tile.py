@@ -12,7 +12,8 @@ EXP_ORDERS = window:longRows pairs (2048:256,...); EXP_ONLY_WINDOWED=1 skips the
 EXP_WINDOWS_FOR_ALL=1 runs the windowed orders on scattered columns too; EXP_ALIGNED=1 orders the rows with spgpuOellOrderAlignedDevice
 (windows counted among the short rows: one window = one workgroup; DESIGN.md section 3.1);
 EXP_DROP_RIDX=1 runs the ordered matrix without its row order (timing only); EXP_FREEZE=1 freezes every ordered matrix first
-(spgpuHellSpmvFreeze: 16-bit column indices).  SPGPU_* knobs pass through.
+(spgpuHellSpmvFreeze: 16-bit column indices); EXP_ADOPT=1 adopts every matrix that comes without an order (spgpuHellSpmvAdopt: the check
+then reports a mismatch -- it compares with the plain kernel's bits; timing and kernel names are what this is for).  SPGPU_* knobs pass through.
 """
 import ctypes as C
 import os
@@ -92,6 +93,9 @@ def run(h, label, forms):
     if os.environ.get("EXP_FREEZE") and r_idx is not None:             # spgpuHellSpmvFreeze first: 16-bit column indices (include/spgpu/tuning.h)
         said = capi.spgpuHellSpmvFreeze(handle, capi.TYPE_CODE[letter], p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]), p(r_idx), rows, 0)
         label = f"{label} FROZEN({said})"
+    if os.environ.get("EXP_ADOPT") and r_idx is None:                   # spgpuHellSpmvAdopt first: the library's ordered, frozen copy (include/spgpu/tuning.h)
+        said = capi.spgpuHellSpmvAdopt(handle, capi.TYPE_CODE[letter], p(h["cM"]), p(h["rP"]), 32, p(h["hack_offsets"]), p(h["rS"]), rows, 0)
+        label = f"{label} ADOPTED({said})"
     for full in forms:
         name = full
         full, _, keep = full.partition("%")         # "auto%32": SPGPU_DEEP_KEEP for this run (same matrix, same process)
@@ -215,6 +219,8 @@ if "powerlaw" in cases:
             orders += [(f"sorted window {p[0]} long>{p[1]}" + (f" cap {p[2]}" if len(p) > 2 else ""), p) for p in pairs]
         if os.environ.get("EXP_ONLY_WINDOWED"):
             orders = orders[2:]
+        if os.environ.get("EXP_ONLY_PLAIN"):
+            orders = orders[:1]
         for name, order in orders:
             if order and len(order) > 2:
                 os.environ["SPGPU_DEEP_CAP"] = str(order[2])

@@ -2,7 +2,7 @@
 """GPU box: the rocprofv3 evidence for the north_star target (ordered power-law HELL fp64 through rIdx), written under
 gpurun_out/profile_<tag>/<tag>_powerlaw_kernel_stats.txt (copy into profiles/).
 
-    python tools/profile_powerlaw.py <tag> [aligned|drift] [plain] [frozen]
+    python tools/profile_powerlaw.py <tag> [aligned|drift] [plain] [frozen] [adopted]
 
   1. rocprofv3 --kernel-trace --stats -- python3 tools/exp_tile.py D 10000000 powerlaw   (EXP_PATTERNS=band,near, AUTO)
   2. per pattern, separate passes: --pmc FETCH_SIZE, --pmc WRITE_SIZE (KiB per launch; FETCH_SIZE x 2 on gfx950 for wide reads)
@@ -20,6 +20,7 @@ tag = sys.argv[1]
 order = sys.argv[2] if len(sys.argv) > 2 else "aligned"
 plain = "plain" in sys.argv[3:]
 frozen = "frozen" in sys.argv[3:]      # spgpuHellSpmvFreeze before the timed calls (EXP_FREEZE=1)
+adopted = "adopted" in sys.argv[3:]    # the rows as they come, spgpuHellSpmvAdopt before the timed calls (EXP_ADOPT=1; implies `plain`, no ordered layouts)
 out = os.path.join(ROOT, "gpurun_out", f"profile_{tag}")
 os.makedirs(out, exist_ok=True)
 base_env = dict(os.environ, TMPDIR="/tmp", EXP_ORDERS="2048:256", EXP_FORMS="auto")
@@ -29,6 +30,11 @@ if not plain:
     base_env["EXP_ONLY_WINDOWED"] = "1"
 if frozen:
     base_env["EXP_FREEZE"] = "1"
+if adopted:
+    base_env.pop("EXP_ONLY_WINDOWED", None)
+    base_env["EXP_ADOPT"] = "1"
+    base_env["EXP_ONLY_PLAIN"] = "1"
+    base_env["EXP_GLOBAL_FORMS"] = "auto"
 exp = ["python3", os.path.join(ROOT, "tools", "exp_tile.py"), "D", "10000000", "powerlaw"]
 KERNELS = ("raggedSpmvKernel", "deepItemsKernel", "deepFinishKernel", "slabSpmvKernel", "planBlocksKernel", "planListKernel", "planPackKernel", "planSlotsKernel",
            "orderedProbeKernel")
@@ -61,7 +67,7 @@ def ragged_kind(name):
     return "<PLAN>" if len(args) >= 10 and args[9].startswith("true") else ""
 
 
-lines.append(f"The north_star target as tools/exp_tile.py runs it (AUTO; order: {order}{', and the rows as they come' if plain else ''}{'; FROZEN: spgpuHellSpmvFreeze first, EXP_FREEZE=1' if frozen else ''}), profiled with")
+lines.append(f"The north_star target as tools/exp_tile.py runs it (AUTO; order: {order}{', and the rows as they come' if plain else ''}{'; FROZEN: spgpuHellSpmvFreeze first, EXP_FREEZE=1' if frozen else ''}{'; the rows as they come, ADOPTED first: spgpuHellSpmvAdopt, EXP_ADOPT=1 (the bit check compares with the PLAIN kernel and says MISMATCH: another order of additions)' if adopted else ''}), profiled with")
 lines.append("  rocprofv3 --kernel-trace --stats -- python3 tools/exp_tile.py D 10000000 powerlaw   (EXP_ORDERS=2048:256 EXP_FORMS=auto EXP_PATTERNS=band,near)")
 lines.append("and, per pattern, in separate passes, --pmc FETCH_SIZE / --pmc WRITE_SIZE (KiB per launch; FETCH_SIZE x 2 on gfx950 for wide reads).")
 d, said, r = run("stats", ["--kernel-trace", "--stats"], "band,near")
@@ -91,7 +97,7 @@ for pattern in ("band", "near"):
         mean = total / counts[(name, counter)]
         gb = mean * 1024 * (2 if counter == "FETCH_SIZE" else 1) * 1e-9
         lines.append(f"  {name:40s} {counter:11s} {mean:12.4g} KiB  ({'x2 = ' if counter == 'FETCH_SIZE' else ''}{gb:.3f} GB)   {counts[(name, counter)]} launches")
-with open(os.path.join(out, f"{tag}_powerlaw_kernel_stats{'_' + order if order != 'aligned' else ''}{'_frozen' if frozen else ''}.txt"), "w") as f:
+with open(os.path.join(out, f"{tag}_powerlaw_kernel_stats{'_' + order if order != 'aligned' else ''}{'_frozen' if frozen else ''}{'_adopted' if adopted else ''}.txt"), "w") as f:
     f.write("\n".join(lines) + "\n")
 print("\n".join(lines))
 for path in glob.glob(os.path.join(out, "**", "*.csv"), recursive=True):
